@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the LIVE reference (build container only).
+
+Imports `/root/reference/solpex` (with an empty `h5py` stub: the reference only
+needs h5py for geometry file I/O, off the hot path), pushes seeded inputs and
+seeded weights through it and stores inputs + expected outputs as small .npz
+fixtures under tests/golden/.  Nothing of the reference's source travels: only
+numbers.  Run:  python tools/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import itertools
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+sys.path.insert(0, "/root/reference")
+import solpex as ref                      # noqa: E402  (the reference)
+from solpex import data as ref_data       # noqa: E402
+from solpex import losses as ref_losses   # noqa: E402
+
+from oracle.unet_ref import UNetCfg, init_state_dict   # noqa: E402
+from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(1)
+torch.manual_seed(0)
+
+
+def ref_model(cfg: UNetCfg, sd):
+    m = ref.UNet(in_ch=cfg.in_ch, out_ch=cfg.out_ch, base=cfg.base, groups_gn=cfg.groups_gn,
+                 dropout=cfg.dropout, P=cfg.P, film_hidden=cfg.film_hidden, z_dim=cfg.z_dim, depth=cfg.depth)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    return m
+
+
+def sd_checksum(sd):
+    return float(sum(float(v.double().abs().sum()) for v in sd.values()))
+
+
+def cfg_dict(cfg):
+    return {f"cfg_{k}": np.asarray(getattr(cfg, k)) for k in
+            ("in_ch", "out_ch", "base", "groups_gn", "P", "film_hidden", "z_dim", "depth")}
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, torch_version=np.asarray(torch.__version__), **out)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def unet_case(name, cfg, B, H, W, seed, loss_kw, store_weights=True, jitter=True, empty_last=True,
+              summary_only=False, use_cw=True):
+    sd = init_state_dict(cfg, seed=seed)
+    model = ref_model(cfg, sd)
+    model.train()
+    bt = make_batch(B, H, W, in_ch=cfg.in_ch, out_ch=cfg.out_ch, P=cfg.P, seed=1234 + seed,
+                    jitter_masks=jitter, empty_last=empty_last)
+    x, y, mask = bt["x"], bt["y"], bt["mask"]
+    params = bt["params"].clone().requires_grad_(True) if cfg.P > 0 else None
+    w_map = torch.from_numpy(ref_losses.edge_weights(mask[0, 0].numpy(), 3.0))[None, None]
+    cw = None
+    if use_cw:
+        cw = torch.tensor((CHANNEL_WEIGHTS_8 * 2)[:cfg.out_ch], dtype=torch.float32)
+    pred, b = model(x, params=params, return_bottleneck=True)
+    loss = ref_losses.masked_weighted_loss(pred, y, mask, w=w_map, channel_weights=cw, **loss_kw)
+    loss.backward()
+    arrs = dict(cfg_dict(cfg))
+    arrs.update(B=B, H=H, W=W, seed=seed, x=x, y=y, mask=mask, w_map=w_map,
+                sd_checksum=sd_checksum(sd), loss=loss.detach())
+    if cw is not None:
+        arrs["cw"] = cw
+    if params is not None:
+        arrs["params"] = params.detach()
+        arrs["dparams"] = params.grad
+    for k, v in loss_kw.items():
+        arrs[f"losskw_{k}"] = np.asarray(v)
+    named = dict(model.named_parameters())
+    if summary_only:
+        arrs["pred"] = pred.detach()
+        arrs["b_norm"] = b.detach().norm()
+        arrs["grad_names"] = np.asarray(list(named.keys()))
+        arrs["grad_norms"] = np.asarray([float(p.grad.norm()) for p in named.values()])
+        arrs["grad_sums"] = np.asarray([float(p.grad.double().sum()) for p in named.values()])
+        # a few full small gradients
+        for k in ("out.weight", "out.bias", "encoders.0.net.0.weight", "film_bot.net.2.bias", "up_convs.2.bias"):
+            if k in named:
+                arrs["grad::" + k] = named[k].grad
+    else:
+        arrs["pred"] = pred.detach()
+        arrs["bott"] = b.detach()
+        for k, p in named.items():
+            if store_weights:
+                arrs["w::" + k] = p.detach()
+            arrs["grad::" + k] = p.grad
+    save(name, **arrs)
+
+
+def latent_case():
+    cfg = UNetCfg(in_ch=1, out_ch=2, base=8, P=5, film_hidden=16, z_dim=4, depth=3)
+    sd = init_state_dict(cfg, seed=3)
+    model = ref_model(cfg, sd).eval()
+    bt = make_batch(2, 16, 16, in_ch=1, out_ch=2, P=5, seed=77, jitter_masks=True)
+    x, params = bt["x"], bt["params"]
+    with torch.no_grad():
+        y, b = model(x, params=params, return_bottleneck=True)
+        b2, skips = model.encode(x, params=params)
+        z = model.project_z(b)
+        z0 = ref.bottleneck_to_z(b)
+        bb = model.unproject_z(z, b.shape)
+        y2 = model.decode_from_bottleneck(x, bb, params=params)
+        y_nop = model(x)            # params=None path: FiLM skipped entirely
+    arrs = dict(cfg_dict(cfg))
+    arrs.update(x=x, params=params, y=y, bott=b, skip0=skips[0], skip2=skips[2], z=z, z0=z0,
+                bb=bb.contiguous(), y2=y2, y_nop=y_nop, seed=3, sd_checksum=sd_checksum(sd))
+    save("unet_latent.npz", **arrs)
+
+
+def loss_cases():
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 2, 3, 12, 10
+    pred = torch.randn(B, C, H, W, generator=g) * 0.3
+    target = pred + torch.randn(B, C, H, W, generator=g) * 0.06     # residuals straddle beta = 0.05
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+    mask[1, :, :, :3] = 0.0
+    w = torch.rand(1, 1, H, W, generator=g)
+    cw = torch.tensor([1.0, 1.5, 0.7])
+    combos = []
+    for base, gmode, gbase, gds, ms in itertools.product(
+            ("huber", "l1", "mse"), ("vector", "magnitude"), ("l1", "huber", "mse"), (1, 2), (0, 1, 2)):
+        combos.append((base, gmode, gbase, gds, ms, True, True, 0.5, 0.1))
+    combos.append(("mse", "vector", "l1", 1, 0, False, False, 0.0, 0.0))    # plain masked MSE
+    combos.append(("huber", "vector", "l1", 2, 0, True, False, 0.5, 0.1))
+    combos.append(("huber", "vector", "l1", 4, 2, False, True, 1.0, 0.2))
+    combos.append(("huber", "vector", "l1", 2, 1, True, True, 0.5, 0.0))    # train_unet before the warm-up
+    losses, grads, desc = [], [], []
+    for (base, gmode, gbase, gds, ms, use_w, use_cw, lam_w, lam_grad) in combos:
+        p = pred.clone().requires_grad_(True)
+        L = ref_losses.masked_weighted_loss(p, target, mask, w=w if use_w else None, lam_grad=lam_grad, lam_w=lam_w,
+                                            base=base, huber_beta=0.05, grad_mode=gmode, grad_base=gbase,
+                                            multiscale=ms, ms_weight=0.5, grad_ds=gds,
+                                            channel_weights=cw if use_cw else None)
+        L.backward()
+        losses.append(float(L))
+        grads.append(p.grad.numpy().copy())
+        desc.append(f"{base}|{gmode}|{gbase}|{gds}|{ms}|{int(use_w)}|{int(use_cw)}|{lam_w}|{lam_grad}")
+    # all-zero mask: denominators clamp to 1e-8
+    z = ref_losses.masked_weighted_loss(pred, target, torch.zeros_like(mask), w=w, lam_grad=0.1, lam_w=0.5,
+                                        grad_ds=2, channel_weights=cw)
+    save("loss_cases.npz", pred=pred, target=target, mask=mask, w=w, cw=cw, desc=np.asarray(desc),
+         losses=np.asarray(losses, dtype=np.float64), grads=np.stack(grads), loss_zero_mask=z,
+         mae_norm=ref_losses.mae_norm(pred, target, mask))
+
+
+def norm_cases():
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 6, 5
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.25).float()
+    keys = ["Te", "ne", "Sp", "lin"]
+    n_log = ref_data.MaskedLogStandardizer(eps=1.0)
+    n_log.mu, n_log.sigma = torch.tensor(2.5), torch.tensor(1.3)
+    n_log2 = ref_data.MaskedLogStandardizer(eps=1e-3)
+    n_log2.mu, n_log2.sigma = torch.tensor(-1.0), torch.tensor(0.7)
+    n_sym = ref_data.MaskedSymLogStandardizer(scale=10.0)
+    n_sym.mu, n_sym.sigma = torch.tensor(0.2), torch.tensor(1.7)
+    n_lin = ref_data.MaskedLinearStandardizer()
+    n_lin.mu, n_lin.sigma = torch.tensor(3.0), torch.tensor(2.0)
+    norm = ref_data.MultiChannelNormalizer(keys, dict(Te=n_log, ne=n_log2, Sp=n_sym, lin=n_lin))
+    y_phys = torch.stack([torch.rand(B, H, W, generator=g) * 100, torch.rand(B, H, W, generator=g) * 5,
+                          torch.randn(B, H, W, generator=g) * 200, torch.randn(B, H, W, generator=g) * 4], dim=1)
+    y_phys[0, 0, 0, 0] = float("nan")
+    y_phys[0, 1, 1, 1] = float("inf")
+    y_phys[1, 2, 2, 2] = float("-inf")
+    y_phys[1, 0, 3, 3] = -4.0
+    z = norm.transform(y_phys, mask)
+    zz = torch.randn(B, 4, H, W, generator=g) * 1.5
+    zz[0, 2, 0, 0] = 80.0       # symexp overflow -> inf -> 0
+    zz[1, 0, 1, 1] = 200.0      # exp overflow -> inf -> 0
+    inv = norm.inverse(zz, mask)
+    pred = zz + 0.1 * torch.randn(B, 4, H, W, generator=g)
+    a, s, px = ref_losses.batch_error_sums_ev(pred, zz, mask, norm)
+    em = np.zeros((20, 14), dtype=np.float32)
+    em[3:17, 2:12] = 1
+    em[8:11, 5:8] = 0
+    ew = ref_losses.edge_weights(em, 3.0)
+    ew0 = ref_losses.edge_weights(np.zeros((4, 4), dtype=np.float32), 3.0)
+    save("norm_cases.npz", mask=mask, y_phys=y_phys, z=z, zz=zz, inv=inv, pred=pred,
+         abs_sum=a, sq_sum=s, px=px, kinds=np.asarray([0, 0, 2, 1]),
+         mus=np.asarray([2.5, -1.0, 0.2, 3.0], dtype=np.float32),
+         sigmas=np.asarray([1.3, 0.7, 1.7, 2.0], dtype=np.float32),
+         epss=np.asarray([1.0, 1e-3, 1e-12, 1e-12]), scales=np.asarray([1.0, 1.0, 10.0, 1.0]),
+         edge_mask=em, edge_w=ew, edge_w_empty=ew0)
+
+
+def adamw_case():
+    g = torch.Generator().manual_seed(9)
+    shapes = [(4, 3, 3, 3), (7,), (5, 6)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    opt = torch.optim.AdamW(ps, lr=3e-3, weight_decay=1e-4)
+    arrs = {"n_tensors": len(ps), "lr": 3e-3, "wd": 1e-4, "clip": 1.0}
+    for i, p in enumerate(ps):
+        arrs[f"p0_{i}"] = p.detach().clone()
+    for step in range(3):
+        gs = [torch.randn(s, generator=g) * (2.0 if step == 0 else 0.05) for s in shapes]
+        for p, gg in zip(ps, gs):
+            p.grad = gg.clone()
+        tot = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+        opt.step()
+        arrs[f"gnorm_{step}"] = tot
+        for i, (p, gg) in enumerate(zip(ps, gs)):
+            arrs[f"g{step}_{i}"] = gg
+            arrs[f"p{step + 1}_{i}"] = p.detach().clone()
+    save("adamw_clip.npz", **arrs)
+
+
+class _ListDS(torch.utils.data.Dataset):
+    def __init__(self, bt):
+        self.bt = bt
+
+    def __len__(self):
+        return self.bt["x"].shape[0]
+
+    def __getitem__(self, i):
+        return {k: v[i] for k, v in self.bt.items()}
+
+
+def train_case():
+    """Two epochs of the reference train_unet on a tiny synthetic loader (fp32, CPU)."""
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=4)
+    tr = make_batch(6, 16, 8, seed=100, jitter_masks=True)
+    va = make_batch(4, 16, 8, seed=101, jitter_masks=True)
+    tl = torch.utils.data.DataLoader(_ListDS(tr), batch_size=2, shuffle=False)
+    vl = torch.utils.data.DataLoader(_ListDS(va), batch_size=2, shuffle=False)
+    keys = [f"c{i}" for i in range(8)]
+    norms = {}
+    for i, k in enumerate(keys):
+        if i % 3 == 0:
+            n = ref_data.MaskedLogStandardizer(eps=1.0); n.mu, n.sigma = torch.tensor(1.0 + 0.1 * i), torch.tensor(0.8)
+        elif i % 3 == 1:
+            n = ref_data.MaskedSymLogStandardizer(scale=5.0); n.mu, n.sigma = torch.tensor(0.1 * i), torch.tensor(1.2)
+        else:
+            n = ref_data.MaskedLinearStandardizer(); n.mu, n.sigma = torch.tensor(0.5), torch.tensor(2.0)
+        norms[k] = n
+    norm = ref_data.MultiChannelNormalizer(keys, norms)
+
+    def mk(in_ch, out_ch):
+        m = ref.UNet(in_ch=in_ch, out_ch=out_ch, base=8, P=5, film_hidden=16, depth=2)
+        m.load_state_dict(sd)
+        return m
+    path = "/tmp/_golden_train.pt"
+    model, hist = ref.train_unet(tl, vl, norm, 1, "cpu", out_ch=8, lam_grad=0.1, lam_w=0.5, epochs=2, base=8,
+                                 model_cls=mk, P=5, film_hidden=16, depth=2, save_path=path, multiscale=1,
+                                 lr_init=2e-3, amp=False, lam_grad_warmup_start=0, lam_grad_warmup_end=1,
+                                 channel_weights=CHANNEL_WEIGHTS_8, log_every=1)
+    fin = model.state_dict()
+    arrs = {f"hist_{k}": np.asarray(v, dtype=np.float64) for k, v in hist.items()}
+    arrs.update(cfg_dict(cfg))
+    arrs["final_checksum"] = sd_checksum(fin)
+    arrs["final::out.weight"] = fin["out.weight"]
+    arrs["final::encoders.0.net.0.weight"] = fin["encoders.0.net.0.weight"]
+    arrs["final::film_bot.net.2.bias"] = fin["film_bot.net.2.bias"]
+    ck = torch.load(path, weights_only=False)
+    arrs["ckpt_keys"] = np.asarray(sorted(ck.keys()))
+    arrs["ckpt_epoch"] = ck["epoch"]
+    arrs["norm_kinds"] = np.asarray([i % 3 for i in range(8)])
+    save("train_history.npz", **arrs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    prod = dict(lam_grad=0.1, lam_w=0.5, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
+                multiscale=0, ms_weight=0.5, grad_ds=2)
+    unet_case("unet_small.npz", UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2),
+              B=3, H=16, W=8, seed=0, loss_kw=prod)
+    unet_case("unet_odd.npz", UNetCfg(in_ch=3, out_ch=4, base=8, P=0, depth=2),
+              B=2, H=13, W=7, seed=1, loss_kw=dict(lam_grad=0.0, lam_w=0.0, base="mse"), empty_last=False)
+    unet_case("unet_d3_ms.npz", UNetCfg(in_ch=1, out_ch=8, base=16, P=5, film_hidden=32, depth=3),
+              B=2, H=32, W=16, seed=2, loss_kw=dict(prod, multiscale=1), store_weights=False, empty_last=False)
+    unet_case("unet_cfgA_summary.npz", UNetCfg(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3),
+              B=2, H=128, W=64, seed=0, loss_kw=prod, store_weights=False, summary_only=True, empty_last=False)
+    latent_case()
+    loss_cases()
+    norm_cases()
+    adamw_case()
+    train_case()
+
+
+if __name__ == "__main__":
+    main()
