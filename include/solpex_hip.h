@@ -1,0 +1,250 @@
+/*
+ * solpex_hip.h -- C ABI of libsolpex_hip.so: hand-written gfx950 (MI355X) HIP kernels for the
+ * SOLPEx conditional U-Net hot path (forward/backward, mask-aware loss, optimizer step).
+ *
+ * The reference (abdoudiaw/Unet, pure Python/PyTorch) has no FFI for this path: its boundary is the
+ * Python module API solpex.models / solpex.losses / solpex.train / solpex.predict, which dispatches
+ * to ATen ops.  Each entry point below therefore cites the reference *Python call site* whose ATen
+ * work it replaces (paths relative to the reference root).  The host-side mirror of that Python API
+ * lives in unet_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless a
+ *    parameter is documented as a host array.  `stream` is a hipStream_t passed as void*.
+ *  - Activations are NHWC ("channels last"): element (b, y, x, c) of a tensor with H x W pixels and
+ *    leading dimension ld lives at ((b*H + y)*W + x)*ld + c.  ld >= C lets a tensor be a channel
+ *    slice of a wider buffer (that is how skip concatenation is made free).
+ *  - dtype: SX_F32 or SX_BF16 = storage type of activations and packed weights, and the MFMA input
+ *    type.  Accumulation, statistics, parameters, gradients of parameters and optimizer state are
+ *    always fp32.
+ *  - Every function returns SX_OK (0) or a negative sx_status; sx_last_error() returns a
+ *    thread-local message.  Work is enqueued on `stream`; no function synchronises the device,
+ *    allocates or frees device memory, or keeps a pointer after it returns.
+ */
+#ifndef SOLPEX_HIP_H_
+#define SOLPEX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_VERSION 100 /* 0.1.0 */
+
+typedef enum sx_status {
+  SX_OK = 0,
+  SX_ERR_INVALID = -1,     /* bad argument (Python wrapper raises ValueError)            */
+  SX_ERR_UNSUPPORTED = -2, /* shape / option outside what the kernels cover (ValueError) */
+  SX_ERR_HIP = -3          /* a HIP runtime call failed (RuntimeError)                   */
+} sx_status;
+
+typedef enum sx_dtype { SX_F32 = 0, SX_BF16 = 1 } sx_dtype;
+
+/* convolution geometry handled by the implicit-GEMM kernels */
+typedef enum sx_conv_mode {
+  SX_CONV3 = 0,   /* 3x3, stride 1, zero pad 1            (nn.Conv2d(.,.,3,padding=1), models.py:66,69) */
+  SX_CONV1 = 1,   /* 1x1                                   (shortcut, models.py:73-77)                   */
+  SX_CONVT_FWD = 2, /* 2x2 stride-2 transposed conv, fprop  (nn.ConvTranspose2d(.,.,2,2), models.py:127)  */
+  SX_CONVT_BWD = 3  /* its data gradient (gather form)                                                   */
+} sx_conv_mode;
+
+int sx_version(void);
+const char* sx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  Replaces nothing in the reference (ATen consumes (Cout,Cin,kh,kw) directly);
+ * the MFMA kernels want K-contiguous, zero-padded tiles in the activation dtype:
+ *   packed[tap][CoutPad][CinPad], CoutPad = roundup(Cout,16), CinPad = roundup(Cin, 64B/sizeof(T)).
+ * `transpose_flip` != 0 builds the data-gradient operand of a 3x3/1x1 conv instead
+ * (roles of Cin/Cout swapped, taps reversed).
+ * sx_packed_weight_elems() returns the element count of the packed tensor.
+ * --------------------------------------------------------------------------------------------- */
+int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k);
+int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
+                        void* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * sx_conv_forward: implicit-GEMM convolution on MFMA (bf16: v_mfma_f32_16x16x32_bf16,
+ * fp32: v_mfma_f32_16x16x4_f32), LDS-staged input halo.  Replaces F.conv2d / conv_transpose2d
+ * forward and the data-gradient half of convolution_backward for
+ *   models.py:66,69 (3x3), :73-77 (1x1 shortcut), :127 (ConvTranspose2d 2x2/2).
+ * y[b,oy,ox,co] (+)= sum_{tap,ci} x[b, iy, ix, ci] * packed[tap][co][ci]  (+ bias[co])
+ *   H, W      : the iteration grid = output pixels (SX_CONVT_FWD: INPUT pixels, output is 2H x 2W)
+ *   Hx, Wx    : pixel dims of the x buffer; Hy, Wy: pixel dims of the y buffer (>= what is written)
+ *   gn_stats  : optional fp32 [B][groups][2]; the epilogue atomically adds sum / sum-of-squares of
+ *               the fp32 results per (sample, group) (GroupNorm statistics, models.py:67,70)
+ *   accumulate: != 0 adds into y instead of overwriting it.
+ * --------------------------------------------------------------------------------------------- */
+int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin, int Cout,
+                    const void* x, int x_ld, int Hx, int Wx, const void* packed, const float* bias,
+                    void* y, int y_ld, int Hy, int Wy, int accumulate, float* gn_stats, int gn_groups,
+                    void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * sx_conv_wgrad: weight gradient as a split-K MFMA GEMM over pixels (weight half of
+ * aten::convolution_backward for models.py:66,69,73-77,127,132).
+ *   dW[tap][a][b] = sum_pixels P[p][a] * Q[q(p,tap)][b]
+ *   SX_CONV3 / SX_CONV1: P = dY (Ca = Cout), Q = X (Cb = Cin)        -> dw laid out (Cout,Cin,kh,kw)
+ *   SX_CONVT_FWD       : P = X  (Ca = Cin),  Q = dY (Cb = Cout, 2Hx2W) -> dw laid out (Cin,Cout,2,2)
+ * Ca/Cb are the (padded) channel counts of the buffers, Ca_out/Cb_out (<= Ca/Cb) the real ones
+ * written to dw.  workspace: sx_conv_wgrad_workspace_bytes() bytes of fp32 slabs (summed in a fixed
+ * order: deterministic).  accumulate != 0 adds into dw.
+ * --------------------------------------------------------------------------------------------- */
+int64_t sx_conv_wgrad_workspace_bytes(int mode, int B, int H, int W, int Ca, int Cb);
+int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
+                  const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                  float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm + SiLU and the DoubleConv block output, forward and backward (models.py:64-71,80,
+ * 152-156).  stats = fp32 [B][groups][2] from sx_conv_forward.  HW = pixels per sample.
+ *   sx_gn_silu_forward : out = SiLU(GN(y))
+ *   sx_block_out_forward: R = (SiLU(GN(y2)) + s) * drop ; out = R * film_g + film_b ; r_out = R
+ *                         (film_g/film_b/drop: fp32 [B][C] or NULL; r_out may be NULL)
+ *   sx_gn_silu_backward: mode 0 through SiLU(GN(y)); mode 1 through the block output.
+ *       sums: zeroed fp32 [B][C][4] = {sum dz*n_hat, sum dz, sum d_out*R, sum d_out} per (b,c)
+ *       (entries 2,3 are the FiLM gamma/beta gradients); dy = gradient w.r.t. y; d_r (mode 1,
+ *       optional) = d_out*film_g*drop = gradient w.r.t. the shortcut branch; dgamma/dbeta optional.
+ * --------------------------------------------------------------------------------------------- */
+int sx_gn_silu_forward(int dtype, int B, int HW, int C, int groups, float eps, const void* y, int y_ld,
+                       const float* stats, const float* gamma, const float* beta, void* out, int out_ld,
+                       void* stream);
+int sx_block_out_forward(int dtype, int B, int HW, int C, int groups, float eps, const void* y2, int y_ld,
+                         const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                         const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                         void* r_out, int r_ld, void* stream);
+int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
+                        int y_ld, const float* stats, const float* gamma, const float* beta,
+                        const void* d_out, int do_ld, const void* r, int r_ld, const float* film_g,
+                        const float* drop, float* sums, void* dy, int dy_ld, void* d_r, int dr_ld,
+                        float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout / pooling helpers.
+ *   sx_pack_input      : (B,C,H,W) fp32 with element strides (sb,sc,sh,sw) -> NHWC dtype, ld>=C zero padded
+ *   sx_unpack_output   : NHWC dtype -> (B,C,H,W) fp32 contiguous
+ *   sx_maxpool2_forward: nn.MaxPool2d(2) (models.py:106,177,181)
+ *   sx_maxpool2_backward_add: dx = dskip (optional) + max-pool backward of dp (first maximum wins, as ATen)
+ *   sx_channel_sum     : out[c] += sum_{b, y<Hs, x<Ws} t[b,y,x,c]  (bias gradients; caller zeroes out)
+ *   sx_global_avg_pool : bottleneck_to_z (models.py:10-12)
+ *   sx_zero_border     : zero channels [0,C) of pixels outside Hin x Win (F.pad strip, models.py:196-197)
+ * --------------------------------------------------------------------------------------------- */
+int sx_pack_input(int dtype, const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int C,
+                  int H, int W, void* out, int out_ld, void* stream);
+int sx_unpack_output(int dtype, const void* in, int in_ld, int B, int C, int H, int W, float* out, void* stream);
+int sx_maxpool2_forward(int dtype, int B, int H, int W, int C, const void* x, int x_ld, void* y, int y_ld, void* stream);
+int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, const void* x, int x_ld, const void* dp,
+                             int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream);
+int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, const void* t, int ld, float* out, void* stream);
+int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, float* z, void* stream);
+int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mask-aware loss (losses.py:60-213), two phases so that data-parallel callers can all-reduce the
+ * batch-global denominators in between.  Pixel-loss kinds: 0 huber (smooth L1), 1 l1, 2 mse.
+ *   sx_loss_prepare: mask (B,1,H,W) fp32, w (H,W) fp32 or NULL -> den[9] = per scale
+ *                    {sum m, sum m*w, sum m_grad}; builds pooled masks in `workspace`.
+ *   sx_loss_forward_backward: pred NHWC `dtype` (ld), target planar fp32 (B,C,H,W);
+ *                    out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = sum mask
+ *                    (mae_norm, losses.py:226-227, is out[1]/max(out[2],1e-8));
+ *                    d_pred (NHWC dtype, ld, channels >= C zeroed) = grad_scale * dloss/dpred, or NULL.
+ * --------------------------------------------------------------------------------------------- */
+int64_t sx_loss_workspace_bytes(int B, int C, int H, int W, int multiscale, int grad_ds);
+int sx_loss_prepare(int B, int C, int H, int W, const float* mask, const float* w, int multiscale,
+                    int grad_ds, float lam_grad, void* workspace, float* den, void* stream);
+int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld,
+                             const float* target, const float* mask, const float* w, const float* cw,
+                             int base_kind, float huber_beta, float lam_w, float lam_grad, int grad_magnitude,
+                             int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
+                             void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Output normalizers and masked metrics (data.py:96-110,139-143,157-163,187-223; losses.py:226-253).
+ * Normalizer kinds per channel; kinds/mu/sigma/eps/scale are HOST arrays of length C (<= SX_MAX_NORM_CH).
+ *   sx_norm_apply      : inverse != 0: normalised -> physical (MultiChannelNormalizer.inverse), else
+ *                        .transform.  `in` has element strides (sb,sc,sh,sw); out is (B,C,H,W) fp32.
+ *   sx_masked_err_sums : denorm == 0: out += {sum|p-t|*m, sum((p-t)*m)^2, sum m over pixels}  (mae_norm)
+ *                        denorm != 0: out += batch_error_sums_ev's {abs_sum, sq_sum, px}.
+ * --------------------------------------------------------------------------------------------- */
+#define SX_MAX_NORM_CH 32
+typedef enum sx_norm_kind { SX_NORM_LOG = 0, SX_NORM_LINEAR = 1, SX_NORM_SYMLOG = 2 } sx_norm_kind;
+int sx_norm_apply(int dtype, int inverse, int B, int C, int H, int W, const void* in, int64_t sb, int64_t sc,
+                  int64_t sh, int64_t sw, const float* mask, const int* kinds, const float* mu, const float* sigma,
+                  const float* eps, const float* scale, float* out, void* stream);
+int sx_masked_err_sums(int dtype, int denorm, int B, int C, int H, int W, const void* pred, int64_t sb, int64_t sc,
+                       int64_t sh, int64_t sw, const float* target, const float* mask, const int* kinds, const float* mu,
+                       const float* sigma, const float* eps, const float* scale, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer (train.py:82,226-233): grad-norm, clip_grad_norm_, AdamW over one flat fp32 arena.
+ * --------------------------------------------------------------------------------------------- */
+int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
+int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float max_norm,
+                  const float* gnorm_sq, float grad_mul, float* gnorm_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-network entry points: UNet.encode / UNet.decode (models.py:173-203) and their backward,
+ * orchestrated in C++ so that a forward or backward pass is ONE call from the host language.
+ *
+ * params / grads: HOST arrays of device pointers to the fp32 parameters (gradients) in the
+ * reference's state_dict order:  encoders.{i}: net.0.weight, net.1.weight, net.1.bias,
+ * net.3.weight, net.4.weight, net.4.bias, shortcut.weight; bot: same 7; up_convs.{j}: weight,
+ * bias; decoders.{j}: same 7; out.weight, out.bias; then (iff P > 0) film_enc.{i}, film_bot,
+ * film_dec.{j}: net.0.weight, net.0.bias, net.2.weight, net.2.bias.  sx_unet_num_params() gives
+ * the table length.
+ * wpack: sx_unet_wpack_bytes() bytes, filled by sx_unet_pack_weights() whenever weights change.
+ * ws   : sx_unet_workspace_bytes() bytes; holds every activation that backward needs, so it must
+ *        stay untouched between a forward and its backward.  sx_unet_view() describes the
+ *        tensors inside it that callers read or write (skips, bottleneck, prediction, gradients).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct sx_unet_desc {
+  int32_t in_ch, out_ch, base, depth, groups_gn, P, film_hidden;
+  int32_t B, H, W;
+  int32_t dtype;      /* sx_dtype of activations / packed weights */
+  int32_t use_film;   /* FiLM applied (params given and P > 0) */
+} sx_unet_desc;
+
+typedef enum sx_unet_tensor {
+  SX_T_INPUT = 0,      /* packed input x, NHWC                                     */
+  SX_T_SKIP = 1,       /* index = encoder level                                    */
+  SX_T_BOTTLENECK = 2,
+  SX_T_PRED = 3,       /* head output, channels padded to a multiple of 8          */
+  SX_T_DPRED = 4,      /* gradient w.r.t. PRED (same layout), written by the caller */
+  SX_T_DSKIP = 5,      /* gradient w.r.t. skip `index` (written by decode backward) */
+  SX_T_DBOTTLENECK = 6,
+  SX_T_FILM_DPARAMS = 7 /* fp32 [B][P]: d loss / d params, accumulated by both backward halves */
+} sx_unet_tensor;
+
+typedef struct sx_view { int64_t offset_bytes; int32_t ld, C, H, W; } sx_view;
+
+int     sx_unet_num_params(const sx_unet_desc* d);
+int64_t sx_unet_wpack_bytes(const sx_unet_desc* d);
+int64_t sx_unet_workspace_bytes(const sx_unet_desc* d);
+int     sx_unet_view(const sx_unet_desc* d, int which, int index, sx_view* out);
+int     sx_unet_pack_weights(const sx_unet_desc* d, const float* const* params, void* wpack, void* stream);
+/* x: (B,in_ch,H,W) fp32 with element strides; film_params: (B,P) fp32 contiguous or NULL */
+int     sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
+                       const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                       const float* film_params, void* stream);
+/* drop: HOST array of `depth` device pointers to fp32 [B][C] dropout factors (entries or the array may be NULL) */
+int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
+                       const float* film_params, const float* const* drop, void* stream);
+/* flags for the backward calls */
+#define SX_BWD_WEIGHT_GRADS 1  /* compute parameter gradients into `grads` */
+#define SX_BWD_ACCUMULATE   2  /* add into `grads` instead of overwriting   */
+#define SX_BWD_ZERO_DPARAMS 4  /* zero FILM_DPARAMS first (the first backward half to run sets it) */
+int     sx_unet_decode_backward(const sx_unet_desc* d, const float* const* params, float* const* grads,
+                                const void* wpack, void* ws, const float* film_params,
+                                const float* const* drop, int flags, void* stream);
+int     sx_unet_encode_backward(const sx_unet_desc* d, const float* const* params, float* const* grads,
+                                const void* wpack, void* ws, const float* film_params, int flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLPEX_HIP_H_ */

@@ -1,0 +1,351 @@
+"""GPU: kernel-level parity of the C-ABI entry points against the CPU oracle / plain torch fp32.
+
+Tolerances (BASELINE.json north_star): fp32 tier <= 1e-4 relative, bf16 tier <= 1e-2 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, max_err, t
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-4, 1: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from unet_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def dev(x, dt=None):
+    x = x.cuda()
+    return x if dt is None else x.to(dt)
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == 1 else torch.float32
+
+
+def nhwc(x, dtype, ld=None):
+    """(B,C,H,W) cpu fp32 -> device NHWC tensor [B,H,W,ld] of the tier's dtype."""
+    B, Cc, H, W = x.shape
+    ld = ld or Cc
+    out = torch.zeros(B, H, W, ld, dtype=tdt(dtype), device="cuda")
+    out[..., :Cc] = x.permute(0, 2, 3, 1).cuda().to(tdt(dtype))
+    return out
+
+
+def from_nhwc(y, Cc):
+    return y[..., :Cc].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dtype):
+    """Round a CPU fp32 tensor to the tier's storage dtype (so both sides see identical inputs)."""
+    return x.to(tdt(dtype)).float()
+
+
+def pack(L, dtype, mode, tflip, w, Cout, Cin, rows, k):
+    n = L.lib().sx_packed_weight_elems(mode, dtype, rows, k)
+    buf = torch.empty(n, dtype=tdt(dtype), device="cuda")
+    wd = w.contiguous().cuda()
+    L.check(L.lib().sx_pack_conv_weight(dtype, mode, tflip, L.ptr(wd), Cout, Cin, L.ptr(buf), L.stream_ptr()))
+    return buf
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 8, 8, 16), (1, 13, 7, 16, 24), (2, 32, 16, 32, 64), (1, 8, 8, 64, 128),
+                                             (3, 5, 3, 8, 8)])
+def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5), dtype)
+    ref = F.conv2d(x, w, padding=1)
+    xd = nhwc(x, dtype)
+    y = torch.empty(B, H, W, Cout, dtype=tdt(dtype), device="cuda")
+    G = min(8, Cout)
+    stats = torch.zeros(B, G, 2, dtype=torch.float32, device="cuda")
+    wp = pack(L, dtype, L.SX_CONV3, 0, w, Cout, Cin, Cout, Cin)
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONV3, B, H, W, Cin, Cout, L.ptr(xd), Cin, H, W, L.ptr(wp), None,
+                                    L.ptr(y), Cout, H, W, 0, L.ptr(stats), G, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(y, Cout), ref) < TOL[dtype]
+    rg = ref.view(B, G, -1)
+    s_ref = torch.stack([rg.sum(-1), (rg * rg).sum(-1)], dim=-1)
+    assert rel_err(stats.cpu(), s_ref) < 1e-4 if dtype == 0 else rel_err(stats.cpu(), s_ref) < 1e-2
+    # data gradient = same kernel on the transposed + flipped pack
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    dref = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1)
+    wpd = pack(L, dtype, L.SX_CONV3, 1, w, Cout, Cin, Cin, Cout)
+    dyd = nhwc(dy, dtype)
+    dx = torch.empty(B, H, W, Cin, dtype=tdt(dtype), device="cuda")
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONV3, B, H, W, Cout, Cin, L.ptr(dyd), Cout, H, W, L.ptr(wpd), None,
+                                    L.ptr(dx), Cin, H, W, 0, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx, Cin), dref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv1x1_bias_accumulate_and_ld(L, dtype):
+    B, H, W, Cin, Cout = 2, 12, 10, 32, 16
+    g = torch.Generator().manual_seed(7)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5, dtype)
+    bias = torch.randn(Cout, generator=g)
+    base = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    ref = F.conv2d(x, w, bias) + base
+    xd = nhwc(x, dtype, ld=Cin + 16)            # input is a channel slice of a wider buffer
+    yd = nhwc(base, dtype, ld=Cout + 8)
+    wp = pack(L, dtype, L.SX_CONV1, 0, w, Cout, Cin, Cout, Cin)
+    bd = bias.cuda()
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONV1, B, H, W, Cin, Cout, L.ptr(xd), Cin + 16, H, W, L.ptr(wp), L.ptr(bd),
+                                    L.ptr(yd), Cout + 8, H, W, 1, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yd, Cout), ref) < TOL[dtype]
+    assert float(yd[..., Cout:].float().abs().max()) == 0.0     # padding channels untouched
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,h,w,Cin,Cout,Ho,Wo", [(2, 4, 4, 32, 16, 8, 8), (1, 3, 1, 16, 8, 7, 3), (2, 8, 4, 64, 32, 16, 8)])
+def test_conv_transpose_forward_and_backward(L, dtype, B, h, w, Cin, Cout, Ho, Wo):
+    g = torch.Generator().manual_seed(h * 10 + Cin)
+    x = q(torch.randn(B, Cin, h, w, generator=g), dtype)
+    wt = q(torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5, dtype)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2)
+    xd = nhwc(x, dtype)
+    # output lands in the lower channel half of a (Ho, Wo) "cat" buffer
+    cat = torch.full((B, Ho, Wo, 2 * Cout), 7.0, dtype=tdt(dtype), device="cuda")
+    wp = pack(L, dtype, L.SX_CONVT_FWD, 0, wt, Cout, Cin, Cout, Cin)
+    bd = bias.cuda()
+    L.check(L.lib().sx_zero_border(dtype, B, Ho, Wo, 2 * h, 2 * w, Cout, L.ptr(cat), 2 * Cout, L.stream_ptr()))
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONVT_FWD, B, h, w, Cin, Cout, L.ptr(xd), Cin, h, w, L.ptr(wp), L.ptr(bd),
+                                    L.ptr(cat), 2 * Cout, Ho, Wo, 0, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = from_nhwc(cat, Cout)
+    padded = F.pad(ref, [0, Wo - 2 * w, 0, Ho - 2 * h])
+    assert rel_err(got, padded) < TOL[dtype]
+    assert float((cat[..., Cout:].float() - 7.0).abs().max()) == 0.0
+    # data gradient (gather form)
+    dy = q(torch.randn(B, Cout, Ho, Wo, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    F.pad(F.conv_transpose2d(xr, wt, bias, stride=2), [0, Wo - 2 * w, 0, Ho - 2 * h]).backward(dy)
+    dyd = nhwc(dy, dtype, ld=2 * Cout)
+    wpb = pack(L, dtype, L.SX_CONVT_BWD, 0, wt, Cout, Cin, Cin, Cout)
+    dx = torch.empty(B, h, w, Cin, dtype=tdt(dtype), device="cuda")
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONVT_BWD, B, h, w, Cout, Cin, L.ptr(dyd), 2 * Cout, Ho, Wo, L.ptr(wpb), None,
+                                    L.ptr(dx), Cin, h, w, 0, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx, Cin), xr.grad) < TOL[dtype]
+    # weight gradient of the transposed conv
+    wr = wt.clone().requires_grad_(True)
+    F.pad(F.conv_transpose2d(x, wr, bias, stride=2), [0, Wo - 2 * w, 0, Ho - 2 * h]).backward(dy)
+    nb = L.lib().sx_conv_wgrad_workspace_bytes(L.SX_CONVT_FWD, B, h, w, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.empty(Cin, Cout, 2, 2, dtype=torch.float32, device="cuda")
+    L.check(L.lib().sx_conv_wgrad(dtype, L.SX_CONVT_FWD, B, h, w, Cin, Cout, Cin, Cout, L.ptr(xd), Cin, L.ptr(dyd), 2 * Cout,
+                                  Ho, Wo, L.ptr(dw), 0, L.ptr(ws), nb, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), wr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode,B,H,W,Cin,Cout", [(0, 2, 16, 8, 8, 16), (0, 3, 13, 7, 16, 24), (0, 2, 32, 16, 32, 64),
+                                                  (0, 1, 16, 16, 64, 128), (1, 2, 12, 10, 32, 16), (0, 4, 32, 32, 8, 32)])
+def test_conv_wgrad(L, dtype, mode, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(H + Cin + mode)
+    k = 3 if mode == 0 else 1
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, padding=k // 2)
+    xd, dyd = nhwc(x, dtype), nhwc(dy, dtype)
+    nb = L.lib().sx_conv_wgrad_workspace_bytes(mode, B, H, W, Cout, Cin)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.full((Cout, Cin, k, k), 1.0, dtype=torch.float32, device="cuda")
+    L.check(L.lib().sx_conv_wgrad(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
+                                  L.ptr(dw), 1, L.ptr(ws), nb, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu() - 1.0, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 8, 16), (3, 7, 5, 24), (2, 32, 16, 64)])
+def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):
+    g = torch.Generator().manual_seed(Cc + H)
+    G = min(8, Cc)
+    y2 = q(torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.3, dtype)
+    s = q(torch.randn(B, Cc, H, W, generator=g), dtype)
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.2 * torch.randn(Cc, generator=g)
+    gf = 1 + 0.3 * torch.randn(B, Cc, generator=g)
+    bf = 0.3 * torch.randn(B, Cc, generator=g)
+    drop = (torch.rand(B, Cc, generator=g) > 0.3).float() / 0.7
+    dO = q(torch.randn(B, Cc, H, W, generator=g), dtype)
+    # oracle
+    yr, sr, gr, br = y2.clone().requires_grad_(True), s.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    gfr, bfr = gf.clone().requires_grad_(True), bf.clone().requires_grad_(True)
+    R = (F.silu(F.group_norm(yr, G, gr, br, eps=1e-5)) + sr) * drop[:, :, None, None]
+    O = R * gfr[:, :, None, None] + bfr[:, :, None, None]
+    O.backward(dO)
+    # device: statistics from the exact inputs
+    yg = y2.view(B, G, -1)
+    stats = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], -1).cuda().contiguous()
+    yd, sd, dOd = nhwc(y2, dtype), nhwc(s, dtype), nhwc(dO, dtype)
+    out = torch.empty(B, H, W, Cc, dtype=tdt(dtype), device="cuda")
+    Rd = torch.empty_like(out)
+    gmd, btd, gfd, bfd, drd = gamma.cuda(), beta.cuda(), gf.cuda().contiguous(), bf.cuda().contiguous(), drop.cuda().contiguous()
+    lib = L.lib()
+    L.check(lib.sx_block_out_forward(dtype, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gmd), L.ptr(btd), L.ptr(sd), Cc,
+                                     L.ptr(gfd), L.ptr(bfd), L.ptr(drd), L.ptr(out), Cc, L.ptr(Rd), Cc, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out, Cc), O.detach()) < TOL[dtype]
+    assert rel_err(from_nhwc(Rd, Cc), R.detach()) < TOL[dtype]
+    sums = torch.zeros(B, Cc, 4, dtype=torch.float32, device="cuda")
+    dy = torch.empty_like(out)
+    dR = torch.empty_like(out)
+    dg = torch.empty(Cc, dtype=torch.float32, device="cuda")
+    db = torch.empty(Cc, dtype=torch.float32, device="cuda")
+    L.check(lib.sx_gn_silu_backward(dtype, 1, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gmd), L.ptr(btd), L.ptr(dOd), Cc,
+                                    L.ptr(Rd), Cc, L.ptr(gfd), L.ptr(drd), L.ptr(sums), L.ptr(dy), Cc, L.ptr(dR), Cc, L.ptr(dg), L.ptr(db),
+                                    0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    tol = TOL[dtype] * (1 if dtype == 0 else 3)
+    assert rel_err(from_nhwc(dy, Cc), yr.grad) < tol
+    assert rel_err(from_nhwc(dR, Cc), sr.grad) < tol
+    assert rel_err(dg.cpu(), gr.grad) < tol and rel_err(db.cpu(), br.grad) < tol
+    assert rel_err(sums[..., 2].cpu(), gfr.grad) < tol and rel_err(sums[..., 3].cpu(), bfr.grad) < tol
+    # mode 0: plain SiLU(GN(y))
+    yr2 = y2.clone().requires_grad_(True)
+    A = F.silu(F.group_norm(yr2, G, gamma, beta, eps=1e-5))
+    A.backward(dO)
+    Ad = torch.empty_like(out)
+    L.check(lib.sx_gn_silu_forward(dtype, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gmd), L.ptr(btd), L.ptr(Ad), Cc, L.stream_ptr()))
+    sums.zero_()
+    L.check(lib.sx_gn_silu_backward(dtype, 0, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gmd), L.ptr(btd), L.ptr(dOd), Cc,
+                                    None, 0, None, None, L.ptr(sums), L.ptr(dy), Cc, None, 0, None, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(Ad, Cc), A.detach()) < TOL[dtype]
+    assert rel_err(from_nhwc(dy, Cc), yr2.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 8, 6, 16), (2, 7, 5, 8)])
+def test_maxpool_forward_backward_first_max_ties(L, dtype, B, H, W, Cc):
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(B, Cc, H, W, generator=g), dtype)
+    x[:, :, :2, :2] = 0.25          # exact ties: the first maximum must take the gradient, as ATen does
+    x[0, 0] = 0.0
+    xr = x.clone().requires_grad_(True)
+    P = F.max_pool2d(xr, 2)
+    dP = q(torch.randn(P.shape, generator=g), dtype)
+    dskip = q(torch.randn(x.shape, generator=g), dtype)
+    P.backward(dP)
+    ref_dx = xr.grad + dskip
+    xd = nhwc(x, dtype, ld=2 * Cc)
+    y = torch.empty(B, H // 2, W // 2, Cc, dtype=tdt(dtype), device="cuda")
+    lib = L.lib()
+    L.check(lib.sx_maxpool2_forward(dtype, B, H, W, Cc, L.ptr(xd), 2 * Cc, L.ptr(y), Cc, L.stream_ptr()))
+    dPd, dsd = nhwc(dP, dtype), nhwc(dskip, dtype)
+    dx = torch.empty(B, H, W, Cc, dtype=tdt(dtype), device="cuda")
+    L.check(lib.sx_maxpool2_backward_add(dtype, B, H, W, Cc, L.ptr(xd), 2 * Cc, L.ptr(dPd), Cc, L.ptr(dsd), Cc, L.ptr(dx), Cc, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(y, Cc), P.detach())
+    assert rel_err(from_nhwc(dx, Cc), ref_dx) < (1e-6 if dtype == 0 else 1e-2)
+
+
+def test_loss_cases_match_golden(L, golden):
+    """Every option combination of masked_weighted_loss: value and gradient vs the reference's vectors."""
+    from unet_amd.losses import masked_weighted_loss, mae_norm
+    g = golden("loss_cases.npz")
+    pred, target, mask, w, cw = (t(g[k]).cuda() for k in ("pred", "target", "mask", "w", "cw"))
+    worst_l = worst_g = 0.0
+    for i, d in enumerate(g["desc"]):
+        base, gmode, gbase, gds, ms, use_w, use_cw, lam_w, lam_grad = str(d).split("|")
+        p = pred.clone().requires_grad_(True)
+        Lv = masked_weighted_loss(p, target, mask, w=w if int(use_w) else None, lam_grad=float(lam_grad), lam_w=float(lam_w),
+                                  base=base, huber_beta=0.05, grad_mode=gmode, grad_base=gbase, multiscale=int(ms),
+                                  ms_weight=0.5, grad_ds=int(gds), channel_weights=cw if int(use_cw) else None)
+        Lv.backward()
+        el = abs(float(Lv) - g["losses"][i]) / abs(g["losses"][i])
+        eg = max_err(p.grad.cpu(), g["grads"][i])
+        worst_l, worst_g = max(worst_l, el), max(worst_g, eg)
+        assert el < 1e-4, (d, float(Lv), g["losses"][i])
+        assert eg < 1e-4, d
+    z = masked_weighted_loss(pred, target, torch.zeros_like(mask), w=w, lam_grad=0.1, lam_w=0.5, grad_ds=2, channel_weights=cw)
+    assert float(z) == float(g["loss_zero_mask"]) == 0.0
+    assert abs(float(mae_norm(pred, target, mask)) - float(g["mae_norm"])) < 1e-5
+    with pytest.raises(ValueError):
+        masked_weighted_loss(pred, target, mask, base="nope")
+    with pytest.raises(ValueError):
+        masked_weighted_loss(pred, target, mask, grad_base="nope")
+
+
+def test_loss_bf16_nhwc_prediction(L, golden):
+    from unet_amd.losses import masked_weighted_loss
+    from oracle import loss_ref
+    g = golden("loss_cases.npz")
+    pred, target, mask, w, cw = (t(g[k]) for k in ("pred", "target", "mask", "w", "cw"))
+    pb = pred.to(torch.bfloat16)
+    pr = pb.float().requires_grad_(True)
+    ref = loss_ref.masked_weighted_loss(pr, target, mask, w=w, lam_grad=0.1, lam_w=0.5, grad_ds=2, channel_weights=cw)
+    ref.backward()
+    pd = pb.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = masked_weighted_loss(pd, target.cuda(), mask.cuda(), w=w.cuda(), lam_grad=0.1, lam_w=0.5, grad_ds=2, channel_weights=cw.cuda())
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-4 * abs(float(ref))
+    assert rel_err(pd.grad.float().cpu(), pr.grad) < 1e-2
+
+
+def test_normalizers_and_error_sums_match_golden(L, golden):
+    from unet_amd import data as D
+    from unet_amd.losses import batch_error_sums_ev, edge_weights
+    g = golden("norm_cases.npz")
+    cls = {0: D.MaskedLogStandardizer, 1: D.MaskedLinearStandardizer, 2: D.MaskedSymLogStandardizer}
+    norms, keys = {}, []
+    for i, (k, mu, sg, ep, sc) in enumerate(zip(g["kinds"], g["mus"], g["sigmas"], g["epss"], g["scales"])):
+        n = cls[int(k)](scale=float(sc), eps=float(ep)) if int(k) == 2 else cls[int(k)](eps=float(ep))
+        n.mu, n.sigma = torch.tensor(float(mu)), torch.tensor(float(sg))
+        norms[f"c{i}"] = n
+        keys.append(f"c{i}")
+    norm = D.MultiChannelNormalizer(keys, norms)
+    mask = t(g["mask"])
+    for devname in ("cpu", "cuda"):
+        z = norm.transform(t(g["y_phys"]).to(devname), mask.to(devname))
+        np.testing.assert_allclose(z.cpu().numpy(), g["z"], rtol=2e-5, atol=2e-6)
+        inv = norm.inverse(t(g["zz"]).to(devname), mask.to(devname))
+        np.testing.assert_allclose(inv.cpu().numpy(), g["inv"], rtol=2e-5, atol=1e-5)
+    a, s, px = batch_error_sums_ev(t(g["pred"]).cuda(), t(g["zz"]).cuda(), mask.cuda(), norm)
+    assert abs(float(a) - float(g["abs_sum"])) < 1e-4 * float(g["abs_sum"])
+    assert abs(float(s) - float(g["sq_sum"])) < 1e-4 * float(g["sq_sum"])
+    assert float(px) == float(g["px"])
+    np.testing.assert_allclose(edge_weights(g["edge_mask"], 3.0), g["edge_w"], rtol=1e-6, atol=1e-7)
+
+
+def test_adamw_clip_matches_golden(L, golden):
+    g = golden("adamw_clip.npz")
+    n = int(g["n_tensors"])
+    ps = [t(g[f"p0_{i}"]) for i in range(n)]
+    sizes = [p.numel() for p in ps]
+    flat_p = torch.cat([p.reshape(-1) for p in ps]).cuda()
+    m = torch.zeros_like(flat_p)
+    v = torch.zeros_like(flat_p)
+    ss = torch.zeros(1, device="cuda")
+    gn = torch.zeros(1, device="cuda")
+    lib = L.lib()
+    for step in range(3):
+        flat_g = torch.cat([t(g[f"g{step}_{i}"]).reshape(-1) for i in range(n)]).cuda()
+        ss.zero_()
+        L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(ss), L.stream_ptr()))
+        L.check(lib.sx_adamw_step(L.ptr(flat_p), L.ptr(flat_g), L.ptr(m), L.ptr(v), flat_p.numel(), float(g["lr"]), 0.9, 0.999,
+                                  1e-8, float(g["wd"]), step + 1, float(g["clip"]), L.ptr(ss), 1.0, L.ptr(gn), L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert abs(float(gn) - float(g[f"gnorm_{step}"])) < 1e-5 * float(g[f"gnorm_{step}"])
+        off = 0
+        for i in range(n):
+            assert max_err(flat_p[off:off + sizes[i]].cpu(), g[f"p{step + 1}_{i}"].reshape(-1)) < 2e-6
+            off += sizes[i]

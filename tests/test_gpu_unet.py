@@ -1,0 +1,198 @@
+"""GPU: whole-network parity.  The HIP U-Net (through the C ABI) against the golden vectors captured
+from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 tier <= 1e-4 relative (per-tensor L2).  bf16 tier <= 1e-2 relative on the prediction
+and the loss (the north-star bar); parameter gradients in the bf16 tier pass through ~20 bf16-stored
+activation/gradient tensors, so per tensor they are held to <= 6e-2 relative L2 and cosine >= 0.998
+against the fp32 reference (tiny-norm tensors are measured against the largest gradient norm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import cfg_from_golden, sd_from_golden, loss_kw_from_golden, t, rel_err, max_err
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg, sd, dropout=0.0):
+    from unet_amd.models import UNet
+    m = UNet(in_ch=cfg.in_ch, out_ch=cfg.out_ch, base=cfg.base, groups_gn=cfg.groups_gn, dropout=dropout, P=cfg.P,
+             film_hidden=cfg.film_hidden, z_dim=cfg.z_dim, depth=cfg.depth)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.cuda()
+
+
+def run_case(g, dtype):
+    from unet_amd.losses import masked_weighted_loss
+    cfg = cfg_from_golden(g)
+    sd = sd_from_golden(g, cfg)
+    model = build(cfg, sd)
+    model.compute_dtype = dtype
+    model.train()
+    x, y, mask = t(g["x"]).cuda(), t(g["y"]).cuda(), t(g["mask"]).cuda()
+    params = t(g["params"]).cuda().requires_grad_(True) if cfg.P > 0 else None
+    cw = t(g["cw"]).cuda() if "cw" in g.files else None
+    pred, b = model(x, params=params, return_bottleneck=True)
+    loss = masked_weighted_loss(pred, y, mask, w=t(g["w_map"]).cuda(), channel_weights=cw, **loss_kw_from_golden(g))
+    loss.backward()
+    torch.cuda.synchronize()
+    return model, pred, b, loss, params
+
+
+@pytest.mark.parametrize("name", ["unet_small.npz", "unet_odd.npz", "unet_d3_ms.npz"])
+def test_unet_fp32_matches_reference_vectors(golden, name):
+    g = golden(name)
+    model, pred, b, loss, params = run_case(g, torch.float32)
+    assert pred.dtype == torch.float32
+    assert rel_err(pred.detach().cpu(), g["pred"]) < 1e-4
+    assert rel_err(b.detach().cpu(), g["bott"]) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    if params is not None:
+        assert rel_err(params.grad.cpu(), g["dparams"]) < 2e-4
+    gmax = max(float(np.linalg.norm(g[k])) for k in g.files if k.startswith("grad::"))
+    for k, p in model.named_parameters():
+        ref = g["grad::" + k]
+        err = float((p.grad.cpu().double() - torch.from_numpy(ref).double()).norm())
+        assert err < 2e-4 * max(float(np.linalg.norm(ref)), 1e-3 * gmax), (k, err, float(np.linalg.norm(ref)))
+
+
+@pytest.mark.parametrize("name", ["unet_small.npz", "unet_d3_ms.npz"])
+def test_unet_bf16_within_tolerance(golden, name):
+    g = golden(name)
+    model, pred, b, loss, params = run_case(g, torch.bfloat16)
+    assert pred.dtype == torch.bfloat16
+    assert rel_err(pred.detach().float().cpu(), g["pred"]) < 1e-2
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    gmax = max(float(np.linalg.norm(g[k])) for k in g.files if k.startswith("grad::"))
+    for k, p in model.named_parameters():
+        ref = g["grad::" + k]
+        gd, rd = p.grad.cpu().double().reshape(-1), torch.from_numpy(ref).double().reshape(-1)
+        err = float((gd - rd).norm())
+        assert err < 6e-2 * max(float(rd.norm()), 0.05 * gmax), (k, err, float(rd.norm()))
+        if float(rd.norm()) > 0.05 * gmax:
+            assert float(torch.dot(gd, rd) / (gd.norm() * rd.norm())) > 0.998, k
+    if params is not None:
+        assert rel_err(params.grad.cpu(), g["dparams"]) < 6e-2
+
+
+def test_unet_cfgA_full_size_summary(golden):
+    """cfg A (base 32, depth 3, 128x64): prediction, loss and per-tensor gradient norms of the reference."""
+    g = golden("unet_cfgA_summary.npz")
+    model, pred, b, loss, params = run_case(g, torch.float32)
+    assert rel_err(pred.detach().cpu(), g["pred"]) < 1e-4
+    assert abs(float(b.detach().float().norm()) - float(g["b_norm"])) < 1e-4 * float(g["b_norm"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    named = dict(model.named_parameters())
+    gmax = float(np.max(g["grad_norms"]))
+    for n, gn in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        assert abs(float(named[n].grad.norm()) - gn) < 5e-4 * max(gn, 1e-3 * gmax), n
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 5e-4, k
+    assert rel_err(params.grad.cpu(), g["dparams"]) < 5e-4
+
+
+def test_latent_helpers_and_decode_paths(golden):
+    g = golden("unet_latent.npz")
+    cfg = cfg_from_golden(g)
+    model = build(cfg, sd_from_golden(g, cfg)).eval()
+    x, params = t(g["x"]).cuda(), t(g["params"]).cuda()
+    with torch.no_grad():
+        y, b = model(x, params=params, return_bottleneck=True)
+        b2, skips = model.encode(x, params=params)
+        z = model.project_z(b)
+        from unet_amd.models import bottleneck_to_z
+        z0 = bottleneck_to_z(b)
+        bb = model.unproject_z(z, b.shape)
+        y2 = model.decode_from_bottleneck(x, bb, params=params)
+        y3 = model.decode(b2, skips, params=params)
+        y_nop = model(x)
+    for got, key in ((y, "y"), (b, "bott"), (skips[0], "skip0"), (skips[2], "skip2"), (z, "z"), (z0, "z0"), (bb, "bb"),
+                     (y2, "y2"), (y3, "y"), (y_nop, "y_nop")):
+        assert rel_err(got.float().cpu(), g[key]) < 1e-4, key
+
+
+def test_dropout_masks_and_grad_accumulation_against_oracle():
+    """Training-mode Dropout2d (explicit masks) and gradient accumulation over two backward passes."""
+    from oracle import unet_ref, loss_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.synth import make_batch
+    from unet_amd.losses import masked_weighted_loss
+    cfg = UNetCfg(in_ch=3, out_ch=4, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=5)
+    bt = make_batch(2, 12, 12, in_ch=3, out_ch=4, P=5, seed=9, jitter_masks=True)
+    model = build(cfg, sd, dropout=0.25).train()
+    torch.manual_seed(0)
+    # capture the masks the model draws by drawing the same stream first
+    torch.manual_seed(123)
+    keep = 0.75
+    masks = [torch.bernoulli(torch.full((2, c), keep, device="cuda")) / keep for c in (16, 8)]
+    torch.manual_seed(123)
+    p = bt["params"].cuda().requires_grad_(True)
+    pred = model(bt["x"].cuda(), params=p)
+    loss = masked_weighted_loss(pred, bt["y"].cuda(), bt["mask"].cuda(), base="mse", lam_grad=0.0, lam_w=0.0)
+    loss.backward()
+    loss2 = masked_weighted_loss(model.eval()(bt["x"].cuda(), params=p), bt["y"].cuda(), bt["mask"].cuda(), base="l1",
+                                 lam_grad=0.0, lam_w=0.0)
+    loss2.backward()                      # accumulates into .grad
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pr = bt["params"].clone().requires_grad_(True)
+    dm = [m.cpu()[:, :, None, None] for m in masks]
+    o1 = unet_ref.unet_forward(sdr, cfg, bt["x"], pr, drop_masks=dm)
+    l1 = loss_ref.masked_weighted_loss(o1, bt["y"], bt["mask"], base="mse", lam_grad=0.0, lam_w=0.0)
+    o2 = unet_ref.unet_forward(sdr, cfg, bt["x"], pr)
+    l2 = loss_ref.masked_weighted_loss(o2, bt["y"], bt["mask"], base="l1", lam_grad=0.0, lam_w=0.0)
+    (l1 + l2).backward()
+    assert abs(float(loss) - float(l1)) < 1e-4 * abs(float(l1))
+    assert abs(float(loss2) - float(l2)) < 1e-4 * abs(float(l2))
+    assert rel_err(p.grad.cpu(), pr.grad) < 3e-4
+    for k, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu(), sdr[k].grad) < 3e-4, k
+
+
+def test_errors_and_boundaries():
+    from unet_amd.models import UNet
+    m = UNet(in_ch=1, out_ch=8, base=8, P=5, depth=2)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 16, 8))                       # CPU tensor: no CPU fallback
+    m = m.cuda()
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, 16, 8, device="cuda"))        # wrong channel count
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 2, 2, device="cuda"))         # grid too small for depth 2
+    with pytest.raises(ValueError):
+        UNet(in_ch=1, out_ch=1, base=12).cuda()(torch.zeros(1, 1, 16, 16, device="cuda"))   # base not a multiple of 8
+    assert m.encoders[0].net[0].in_channels == 1          # read by scripts/train_inverse_mlp.py:102
+    assert len(m.state_dict()) == 61
+
+
+def test_full_size_properties_cfg2_shape():
+    """cfg 2 shape (B=64, 128x64, bf16): size-independent properties instead of an oracle run.
+    (1) samples are independent: a batch of 64 equals the same samples run 8 at a time (up to the
+        order of the fp32 atomic adds in the GroupNorm statistics);
+    (2) a zero mask gives zero loss and zero gradients; (3) everything is finite."""
+    from unet_amd.models import UNet
+    from unet_amd.synth import make_batch
+    from unet_amd.losses import masked_weighted_loss
+    torch.manual_seed(0)
+    model = UNet(in_ch=1, out_ch=8, base=32, P=5, depth=3).cuda()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".net.2." in n and "film" in n:
+                p.normal_(0, 0.05)
+    model.compute_dtype = torch.bfloat16
+    bt = make_batch(64, 128, 64, seed=1234)
+    x, y, m, p = (bt[k].cuda() for k in ("x", "y", "mask", "params"))
+    with torch.no_grad():
+        full = model(x, params=p).float()
+        parts = torch.cat([model(x[i:i + 8], params=p[i:i + 8]).float() for i in range(0, 64, 8)])
+    assert torch.isfinite(full).all()
+    assert rel_err(full.cpu(), parts.cpu()) < 2e-3
+    model.train()
+    pred = model(x, params=p)
+    loss = masked_weighted_loss(pred, y, torch.zeros_like(m), lam_grad=0.1, lam_w=0.5, grad_ds=2)
+    loss.backward()
+    assert float(loss) == 0.0
+    assert all(float(q.grad.abs().max()) == 0.0 for q in model.parameters())

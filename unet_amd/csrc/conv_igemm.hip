@@ -1,0 +1,358 @@
+// Implicit-GEMM convolution on gfx950 MFMA with an LDS-staged input halo.
+//
+// One kernel covers the four geometries of the U-Net (include/solpex_hip.h, sx_conv_mode):
+//   3x3 pad 1, 1x1, ConvTranspose2d(2,2) fprop (a 1x1 GEMM with a pixel-shuffle store) and its data
+//   gradient (a 4-tap gather).  Data gradients of the 3x3 / 1x1 convs are the same kernel run on
+//   the transposed+flipped packed weights.
+//
+// GEMM orientation: A = packed weights (rows = output channels), B = input pixels (cols), so the
+// MFMA result D[channel 4g+r][pixel l&15] leaves every lane with 4 CONSECUTIVE channels of one
+// pixel -> one 8-byte (bf16) / 16-byte (fp32) NHWC store per tile, and per-channel GroupNorm
+// partial sums are a 16-lane reduction.
+//
+// K is walked in 64-byte chunks (32 bf16 / 16 fp32 channels).  Per chunk a block stages
+//   - the input halo tile  [(TH-1)*s+taph][(TW-1)*s+tapw] pixels x 64 B   and
+//   - the weight slice     [ntaps][BMC rows] x 64 B
+// into LDS (rows padded to 96 B: conflict-free for the ds_read_b128 fragment reads), then every
+// wave runs ntaps x MI x NI MFMAs on fragments read straight from those two images.
+#include "sx_common.h"
+
+namespace sx {
+
+static constexpr int ROWB = 96;   // LDS bytes per staged row (64 payload + 32 pad)
+
+struct ConvArgs {
+  const void* x; const void* w; void* y; const float* bias; float* gn_stats;
+  int B, H, W;
+  int Hx, Wx, x_ld;
+  int Hy, Wy, y_ld;
+  int K, KPad;        // GEMM-K channels per tap (real / padded)
+  int R, RPad, RTot;  // output channels (real / padded per tap group / rows per tap in `w`)
+  int ntaps, tapw;
+  int in_scale, pad;
+  int shuffle, accumulate;
+  int tw_log2, TW, TH, LW, LH;
+  int tiles_x, tiles_y;
+  int cpg;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  __device__ static __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // 16 k-values per chunk: lane group g owns k = 4g..4g+3, MFMA step s consumes element s of
+  // every group (a consistent permutation of k on both operands).
+  __device__ static __forceinline__ f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T, int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  typedef typename Elem<T>::Vec Vec;
+  constexpr int EPL = Elem<T>::EPL, CK = Elem<T>::CK;
+  constexpr int BMC = WM * MI * 16;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WN * NI * 16 == 128, "128-pixel tile");
+  extern __shared__ __align__(16) char smem[];
+  char* sm_pix = smem;
+  char* sm_w = smem + a.LH * a.LW * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int n = lane & 15, g = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int tx_i = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty_i = bid % a.tiles_y; bid /= a.tiles_y;
+  const int b = bid;
+  const int ty0 = ty_i * a.TH, tx0 = tx_i * a.TW;
+  const int cb = blockIdx.y * BMC;
+
+  int pix_off[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = (wn * NI + i) * 16 + n;
+    const int py = m >> a.tw_log2, px = m & (a.TW - 1);
+    pix_off[i] = ((py * a.in_scale) * a.LW + px * a.in_scale) * ROWB + g * 16;
+  }
+  int w_off[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) w_off[j] = ((wm * MI + j) * 16 + n) * ROWB + g * 16;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+  const int npix_pieces = a.LH * a.LW * 4;
+  const int nw_pieces = a.ntaps * BMC * 4;
+  const int iy0 = ty0 * a.in_scale - a.pad, ix0 = tx0 * a.in_scale - a.pad;
+
+  for (int kc = 0; kc < a.KPad; kc += CK) {
+    __syncthreads();
+    for (int p = tid; p < npix_pieces; p += 256) {
+      const int r = p >> 2, q = p & 3;
+      const int ly = r / a.LW, lx = r - ly * a.LW;
+      const int iy = iy0 + ly, ix = ix0 + lx;
+      const int c = kc + q * EPL;
+      Vec v = {};
+      if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.K)
+        v = *reinterpret_cast<const Vec*>(xg + ((int64_t)(b * a.Hx + iy) * a.Wx + ix) * a.x_ld + c);
+      *reinterpret_cast<Vec*>(sm_pix + r * ROWB + q * 16) = v;
+    }
+    for (int p = tid; p < nw_pieces; p += 256) {
+      const int r = p >> 2, q = p & 3;
+      const int tap = r / BMC, row = r - tap * BMC;
+      Vec v = {};
+      if (cb + row < a.RTot)
+        v = *reinterpret_cast<const Vec*>(wg + ((int64_t)tap * a.RTot + cb + row) * a.KPad + kc + q * EPL);
+      *reinterpret_cast<Vec*>(sm_w + r * ROWB + q * 16) = v;
+    }
+    __syncthreads();
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int tyy = tap / a.tapw, txx = tap - tyy * a.tapw;
+      const int toff = (tyy * a.LW + txx) * ROWB;
+      const char* wt = sm_w + tap * BMC * ROWB;
+      Vec A[MI], Bf[NI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) A[j] = *reinterpret_cast<const Vec*>(wt + w_off[j]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) Bf[i] = *reinterpret_cast<const Vec*>(sm_pix + pix_off[i] + toff);
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[j][i] = Mma<T>::run(A[j], Bf[i], acc[j][i]);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  T* __restrict__ yg = reinterpret_cast<T*>(a.y);
+  const bool do_stats = a.gn_stats != nullptr;
+  float* sm_stat = reinterpret_cast<float*>(smem);   // [WN][BMC][2], reused after the K loop
+  if (do_stats) __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int cl = (wm * MI + j) * 16 + 4 * g;   // channel within the block tile
+    const int c0 = cb + cl;
+    int co = c0, tap = 0;
+    if (a.shuffle) { tap = c0 / a.RPad; co = c0 - tap * a.RPad; }
+    const bool cvalid = (c0 < a.RTot) && (co < a.R);
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && cvalid) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int m = (wn * NI + i) * 16 + n;
+      const int py = m >> a.tw_log2, px = m & (a.TW - 1);
+      int oy = ty0 + py, ox = tx0 + px;
+      const bool pvalid = (oy < a.H) && (ox < a.W);
+      if (a.shuffle) { oy = 2 * oy + (tap >> 1); ox = 2 * ox + (tap & 1); }
+      f32x4 v = acc[j][i] + bias;
+      if (pvalid && cvalid) {
+        T* dst = yg + ((int64_t)(b * a.Hy + oy) * a.Wy + ox) * a.y_ld + co;
+        if (a.accumulate) v += load4(dst);
+        store4(dst, v);
+        if (do_stats) { s1 += v; s2 += v * v; }
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = sum16(s1[r]), t2 = sum16(s2[r]);
+        if (n == 0) {
+          sm_stat[(wn * BMC + cl + r) * 2 + 0] = t1;
+          sm_stat[(wn * BMC + cl + r) * 2 + 1] = t2;
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    if (tid < BMC) {
+      const int c = cb + tid;
+      const int cend = min(a.R, cb + BMC);
+      if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
+        const int grp = c / a.cpg;
+        float t1 = 0.f, t2 = 0.f;
+        for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
+#pragma unroll
+          for (int w = 0; w < WN; ++w) {
+            t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
+            t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
+          }
+        const int G = a.R / a.cpg;
+        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
+        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
+      }
+    }
+  }
+}
+
+template <typename T, int MI, int NI, int WM, int WN>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int BMC = WM * MI * 16;
+  size_t smem = (size_t)(a.LH * a.LW + a.ntaps * BMC) * ROWB;
+  size_t stat_bytes = (size_t)WN * BMC * 2 * sizeof(float);
+  if (smem < stat_bytes) smem = stat_bytes;
+  if (smem > 160 * 1024) { set_error("conv tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
+  auto kern = conv_igemm_kernel<T, MI, NI, WM, WN>;
+  static size_t configured = 0;   // monotone max; a benign race re-sets the same attribute
+  if (smem > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv)");
+    configured = 160 * 1024;
+  }
+  dim3 grid(a.tiles_x * a.tiles_y * a.B, cdiv(a.RTot, BMC));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  SX_LAUNCH_CHECK("conv_igemm");
+  return SX_OK;
+}
+
+template <typename T>
+static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
+  if (a.RTot <= 16) return launch_conv<T, 1, 2, 1, 4>(a, st);
+  if (a.RTot <= 32) return launch_conv<T, 2, 2, 1, 4>(a, st);
+  return launch_conv<T, 2, 4, 2, 2>(a, st);
+}
+
+// ------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int tflip,
+                                   int Cout, int Cin, int ntaps, int RTot, int RPad, int KPad, int64_t total) {
+  // out[tap][row][k]
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % KPad);
+    const int64_t t2 = idx / KPad;
+    const int row = (int)(t2 % RTot);
+    const int tap = (int)(t2 / RTot);
+    float v = 0.f;
+    if (mode == SX_CONV3 || mode == SX_CONV1) {
+      const int nt = (mode == SX_CONV3) ? 9 : 1;
+      if (!tflip) {            // rows = Cout, k = Cin : w[co][ci][tap]
+        if (row < Cout && k < Cin) v = w[((int64_t)row * Cin + k) * nt + tap];
+      } else {                 // rows = Cin, k = Cout : w[co=k][ci=row][nt-1-tap]
+        if (row < Cin && k < Cout) v = w[((int64_t)k * Cin + row) * nt + (nt - 1 - tap)];
+      }
+    } else if (mode == SX_CONVT_FWD) {   // w[ci][co][ty][tx]; rows = tp*RPad + co, k = ci
+      const int tp = row / RPad, co = row - tp * RPad;
+      if (co < Cout && k < Cin) v = w[((int64_t)k * Cout + co) * 4 + tp];
+    } else {                             // SX_CONVT_BWD: rows = ci, k = co, taps = 4
+      if (row < Cin && k < Cout) v = w[((int64_t)row * Cout + k) * 4 + tap];
+    }
+    out[idx] = from_f32<T>(v);
+  }
+}
+
+struct PackGeom { int ntaps, R, K, RPad, RTot, KPad; };
+static PackGeom pack_geom(int mode, int dtype, int tflip, int Cout, int Cin) {
+  const int CK = dtype == SX_BF16 ? 32 : 16;
+  PackGeom p;
+  if (mode == SX_CONV3 || mode == SX_CONV1) {
+    p.ntaps = mode == SX_CONV3 ? 9 : 1;
+    p.R = tflip ? Cin : Cout;
+    p.K = tflip ? Cout : Cin;
+    p.RPad = round_up(p.R, 16);
+    p.RTot = p.RPad;
+  } else if (mode == SX_CONVT_FWD) {
+    p.ntaps = 1; p.R = Cout; p.K = Cin; p.RPad = round_up(Cout, 16); p.RTot = 4 * p.RPad;
+  } else {
+    p.ntaps = 4; p.R = Cin; p.K = Cout; p.RPad = round_up(Cin, 16); p.RTot = p.RPad;
+  }
+  p.KPad = round_up(p.K, CK);
+  return p;
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k) {
+  // c_rows / c_k are the GEMM's output / reduction channel counts (after any transpose).
+  const int CK = dtype == SX_BF16 ? 32 : 16;
+  const int ntaps = mode == SX_CONV3 ? 9 : (mode == SX_CONVT_BWD ? 4 : 1);
+  const int rtot = round_up(c_rows, 16) * (mode == SX_CONVT_FWD ? 4 : 1);
+  return (int64_t)ntaps * rtot * round_up(c_k, CK);
+}
+
+extern "C" int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
+                                   void* packed, void* stream) {
+  SX_REQUIRE(w && packed, "sx_pack_conv_weight: null pointer");
+  SX_REQUIRE(mode >= SX_CONV3 && mode <= SX_CONVT_BWD, "sx_pack_conv_weight: bad mode %d", mode);
+  SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_pack_conv_weight: bad dtype %d", dtype);
+  PackGeom p = pack_geom(mode, dtype, transpose_flip, Cout, Cin);
+  const int64_t total = (int64_t)p.ntaps * p.RTot * p.KPad;
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 2048);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)packed, mode,
+                       transpose_flip, Cout, Cin, p.ntaps, p.RTot, p.RPad, p.KPad, total);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)packed, mode,
+                       transpose_flip, Cout, Cin, p.ntaps, p.RTot, p.RPad, p.KPad, total);
+  SX_LAUNCH_CHECK("pack_weight");
+  return SX_OK;
+}
+
+extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin, int Cout,
+                               const void* x, int x_ld, int Hx, int Wx, const void* packed, const float* bias,
+                               void* y, int y_ld, int Hy, int Wy, int accumulate, float* gn_stats, int gn_groups,
+                               void* stream) {
+  SX_REQUIRE(x && packed && y, "sx_conv_forward: null pointer");
+  SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_forward: bad dtype %d", dtype);
+  SX_REQUIRE(mode >= SX_CONV3 && mode <= SX_CONVT_BWD, "sx_conv_forward: bad mode %d", mode);
+  SX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sx_conv_forward: empty problem");
+  const int EPL = dtype == SX_BF16 ? 8 : 4, CK = dtype == SX_BF16 ? 32 : 16;
+  if (Cin % EPL || x_ld % EPL || Cout % 4 || y_ld % 4) {
+    set_error("sx_conv_forward: channel counts must be multiples of %d (in) / 4 (out): Cin=%d x_ld=%d Cout=%d y_ld=%d",
+              EPL, Cin, x_ld, Cout, y_ld);
+    return SX_ERR_UNSUPPORTED;
+  }
+  SX_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 8) == 0,
+             "sx_conv_forward: misaligned pointer");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = packed; a.y = y; a.bias = bias; a.gn_stats = gn_stats;
+  a.B = B; a.H = H; a.W = W; a.Hx = Hx; a.Wx = Wx; a.x_ld = x_ld; a.Hy = Hy; a.Wy = Wy; a.y_ld = y_ld;
+  a.K = Cin; a.KPad = round_up(Cin, CK);
+  a.R = Cout; a.RPad = round_up(Cout, 16); a.RTot = a.RPad;
+  a.accumulate = accumulate;
+  switch (mode) {
+    case SX_CONV3: a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1; break;
+    case SX_CONV1: a.ntaps = 1; a.tapw = 1; a.in_scale = 1; a.pad = 0; break;
+    case SX_CONVT_FWD: a.ntaps = 1; a.tapw = 1; a.in_scale = 1; a.pad = 0; a.shuffle = 1; a.RTot = 4 * a.RPad; break;
+    default: a.ntaps = 4; a.tapw = 2; a.in_scale = 2; a.pad = 0; break;
+  }
+  if (mode == SX_CONVT_FWD)
+    SX_REQUIRE(Hx >= H && Wx >= W && Hy >= 2 * H && Wy >= 2 * W, "sx_conv_forward: convT fwd buffer dims");
+  else if (mode == SX_CONVT_BWD)
+    SX_REQUIRE(Hx >= 2 * H && Wx >= 2 * W && Hy >= H && Wy >= W, "sx_conv_forward: convT bwd buffer dims");
+  else
+    SX_REQUIRE(Hx == H && Wx == W && Hy >= H && Wy >= W, "sx_conv_forward: buffer dims");
+  if (gn_stats) {
+    SX_REQUIRE(gn_groups > 0 && Cout % gn_groups == 0 && !a.shuffle && !accumulate,
+               "sx_conv_forward: bad GroupNorm statistics request");
+    a.cpg = Cout / gn_groups;
+  }
+  a.tw_log2 = W > 8 ? 4 : (W > 4 ? 3 : 2);
+  a.TW = 1 << a.tw_log2;
+  a.TH = 128 / a.TW;
+  const int taph = a.ntaps / a.tapw;
+  a.LW = (a.TW - 1) * a.in_scale + a.tapw;
+  a.LH = (a.TH - 1) * a.in_scale + taph;
+  a.tiles_x = cdiv(W, a.TW);
+  a.tiles_y = cdiv(H, a.TH);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SX_BF16 ? conv_dispatch<bf16>(a, st) : conv_dispatch<float>(a, st);
+}

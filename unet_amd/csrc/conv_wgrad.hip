@@ -1,0 +1,325 @@
+// Weight gradients of the 3x3 / 1x1 / ConvTranspose2d(2,2) layers as a split-K MFMA GEMM whose
+// reduction dimension is the pixel index:
+//     dW[tap][a][b] = sum_{n,py,px} P[n,py,px,a] * Q[n, qy(py,tap), qx(px,tap), b]
+//   conv3x3 : P = dY (a = co), Q = X  (b = ci), q = p + tap - 1 (zero outside)   -> W[co][ci][ty][tx]
+//   conv1x1 : same with one tap
+//   convT   : P = X  (a = ci), Q = dY (b = co), q = 2p + tap                    -> W[ci][co][ty][tx]
+// Replaces the weight half of aten::convolution_backward for models.py:66,69,73-77,127.
+//
+// Both operands are pixel-major in memory (NHWC) but the MFMA wants 8 consecutive K (= pixels)
+// per lane, i.e. the transposed image.  bf16: tiles are staged pixel-major in LDS and fragments are
+// read with ds_read_b64_tr_b16 (hardware transpose).  fp32: v_mfma_f32_16x16x4_f32 takes ONE k per
+// lane, so a plain ds_read_b32 of [pixel][channel] rows is already the right fragment.
+//
+// Grid: (a-tiles of 16*MI) x (b-tiles of 64) x nsplit.  Every split walks its share of the
+// 128-pixel tiles and writes an fp32 slab; a second kernel sums the slabs in a fixed order
+// (deterministic) straight into the parameter-gradient tensor in PyTorch layout.
+#include "sx_common.h"
+
+namespace sx {
+
+struct WgradArgs {
+  const void* P; const void* Q; float* slab;
+  int B, H, W;          // P pixel grid
+  int Hq, Wq;           // Q pixel dims
+  int p_ld, q_ld;
+  int Ca, Cb, CaPad, CbPad;
+  int ntaps, tapw, q_scale, pad;
+  int tw_log2, TW, TH, LW, LH, TP;   // TP = pixels per tile (multiple of 32)
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int nbf;              // b fragments (16 channels) in this block's b tile
+};
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<bf16> { static constexpr int PADB = 16; };
+template <> struct WgTraits<float> { static constexpr int PADB = 64; };
+
+// A/B fragment for the 32-pixel k-step starting at tile pixel k0, 16 channels starting at byte
+// offset ch_off of each pixel row.  pixel_row(k) maps a tile pixel to its LDS row.
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+  typedef bf16x8 V;
+  // rowaddr[jb] : LDS byte address this lane supplies for k = 8g + 4jb + q, columns 4p..4p+3
+  __device__ static __forceinline__ V read(const char* a0, const char* a1) {
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a1);
+    union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+    u.s.l = lo; u.s.h = hi;
+    return u.v;
+  }
+};
+
+template <typename T, int MI, int ITEMS>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  typedef typename Elem<T>::Vec Vec;
+  constexpr int EPL = Elem<T>::EPL;
+  constexpr int BA = MI * 16, BB = 64;
+  constexpr int PROW = BA * (int)sizeof(T) + WgTraits<T>::PADB;
+  constexpr int QROW = BB * (int)sizeof(T) + WgTraits<T>::PADB;
+  extern __shared__ __align__(16) char smem[];
+  char* sP = smem;
+  char* sQ = smem + a.TP * PROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
+  const int split = blockIdx.z;
+  const int nitems = a.ntaps * a.nbf;
+
+  // per-item constants
+  int it_tap_off[ITEMS], it_bf[ITEMS];
+  bool it_valid[ITEMS];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const int it = wid * ITEMS + t;
+    it_valid[t] = it < nitems;
+    const int itc = it_valid[t] ? it : 0;
+    const int tap = itc / a.nbf;
+    it_bf[t] = itc - tap * a.nbf;
+    const int tyy = tap / a.tapw, txx = tap - tyy * a.tapw;
+    it_tap_off[t] = (tyy * a.LW + txx) * QROW;
+  }
+
+  f32x4 acc[ITEMS][MI];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const T* __restrict__ Pg = reinterpret_cast<const T*>(a.P);
+  const T* __restrict__ Qg = reinterpret_cast<const T*>(a.Q);
+  constexpr int PPIECES = BA * (int)sizeof(T) / 16, QPIECES = BB * (int)sizeof(T) / 16;
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx_i = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty_i = tt % a.tiles_y; tt /= a.tiles_y;
+    const int bimg = tt;
+    const int ty0 = ty_i * a.TH, tx0 = tx_i * a.TW;
+    __syncthreads();
+    for (int p = tid; p < a.TP * PPIECES; p += 256) {
+      const int m = p / PPIECES, q = p - m * PPIECES;
+      const int py = ty0 + (m >> a.tw_log2), px = tx0 + (m & (a.TW - 1));
+      const int c = a0 + q * EPL;
+      Vec v = {};
+      if (py < a.H && px < a.W && c < a.Ca)
+        v = *reinterpret_cast<const Vec*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
+      *reinterpret_cast<Vec*>(sP + m * PROW + q * 16) = v;
+    }
+    const int qy0 = ty0 * a.q_scale - a.pad, qx0 = tx0 * a.q_scale - a.pad;
+    for (int p = tid; p < a.LH * a.LW * QPIECES; p += 256) {
+      const int r = p / QPIECES, q = p - r * QPIECES;
+      const int ly = r / a.LW, lx = r - ly * a.LW;
+      const int qy = qy0 + ly, qx = qx0 + lx;
+      const int c = b0 + q * EPL;
+      Vec v = {};
+      if (qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
+        v = *reinterpret_cast<const Vec*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
+      *reinterpret_cast<Vec*>(sQ + r * QROW + q * 16) = v;
+    }
+    __syncthreads();
+
+    if constexpr (sizeof(T) == 2) {
+      const int q4 = n >> 2, p4 = n & 3;
+      for (int ks = 0; ks < (a.TP >> 5); ++ks) {
+        // this lane supplies rows k = ks*32 + 8g + 4jb + q4, jb = 0,1
+        const int k0 = ks * 32 + 8 * g + q4, k1 = k0 + 4;
+        const char* pa0 = sP + k0 * PROW + p4 * 8;
+        const char* pa1 = sP + k1 * PROW + p4 * 8;
+        bf16x8 A[MI];
+#pragma unroll
+        for (int j = 0; j < MI; ++j) A[j] = Frag<bf16>::read(pa0 + j * 32, pa1 + j * 32);
+        const int r0 = (((k0 >> a.tw_log2) * a.q_scale) * a.LW + (k0 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
+        const int r1 = (((k1 >> a.tw_log2) * a.q_scale) * a.LW + (k1 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+          // every lane issues the transposed read (EXEC must be full); invalid items read item 0
+          bf16x8 Bf = Frag<bf16>::read(sQ + r0 + it_tap_off[t] + it_bf[t] * 32, sQ + r1 + it_tap_off[t] + it_bf[t] * 32);
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bf, acc[t][j], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < (a.TP >> 2); ++ks) {
+        const int k = ks * 4 + g;      // one pixel per lane group
+        float A[MI];
+#pragma unroll
+        for (int j = 0; j < MI; ++j) A[j] = *reinterpret_cast<const float*>(sP + k * PROW + (j * 16 + n) * 4);
+        const int r = (((k >> a.tw_log2) * a.q_scale) * a.LW + (k & (a.TW - 1)) * a.q_scale) * QROW + n * 4;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+          const float Bv = *reinterpret_cast<const float*>(sQ + r + it_tap_off[t] + it_bf[t] * 64);
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j], Bv, acc[t][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // slab[split][tap][a][b]: lane holds rows a = 4g + r, column b = n of each 16x16 tile
+  float* slab = a.slab + (int64_t)split * a.ntaps * a.CaPad * a.CbPad;
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    if (!it_valid[t]) continue;
+    const int it = wid * ITEMS + t;
+    const int tap = it / a.nbf, bf = it - tap * a.nbf;
+    const int bcol = b0 + bf * 16 + n;
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int arow = a0 + j * 16 + 4 * g + r;
+        if (arow < a.CaPad && bcol < a.CbPad)
+          slab[((int64_t)tap * a.CaPad + arow) * a.CbPad + bcol] = acc[t][j][r];
+      }
+  }
+}
+
+// out[a*sa + b*sb + tap*st] (+)= sum_s slab[s][tap][a][b]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntaps,
+                                    int Ca, int Cb, int CaPad, int CbPad, int64_t sa, int64_t sb, int64_t st,
+                                    int accumulate) {
+  const int64_t total = (int64_t)ntaps * Ca * Cb;
+  const int64_t slab_sz = (int64_t)ntaps * CaPad * CbPad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % Cb);
+    const int64_t t2 = i / Cb;
+    const int aa = (int)(t2 % Ca);
+    const int tap = (int)(t2 / Ca);
+    const float* src = slab + ((int64_t)tap * CaPad + aa) * CbPad + b;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += src[k * slab_sz];
+    float* dst = out + aa * sa + b * sb + tap * st;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+struct WgPlan { int MI, nbf, items, a_tiles, b_tiles, nsplit, tiles_per_split; size_t ws_bytes; };
+
+static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const WgradArgs& g) {
+  WgPlan p;
+  const int CaPad = round_up(Ca, 16), CbPad = round_up(Cb, 16);
+  p.MI = CaPad >= 64 ? 4 : 2;
+  p.a_tiles = cdiv(CaPad, p.MI * 16);
+  p.b_tiles = cdiv(CbPad, 64);
+  p.nbf = std::min(4, CbPad / 16);
+  p.items = cdiv(g.ntaps * p.nbf, 4);
+  const int ntiles = B * g.tiles_x * g.tiles_y;
+  const size_t slab1 = (size_t)g.ntaps * CaPad * CbPad * sizeof(float);
+  int ns = std::max(1, 1024 / (p.a_tiles * p.b_tiles));
+  ns = std::min(ns, ntiles);
+  ns = std::min<int>(ns, std::max<size_t>(1, ((size_t)32 << 20) / slab1));
+  p.tiles_per_split = cdiv(ntiles, ns);
+  p.nsplit = cdiv(ntiles, p.tiles_per_split);
+  p.ws_bytes = slab1 * p.nsplit;
+  return p;
+}
+
+static int wgrad_geom(int mode, int dtype, int B, int H, int W, WgradArgs& a) {
+  switch (mode) {
+    case SX_CONV3: a.ntaps = 9; a.tapw = 3; a.q_scale = 1; a.pad = 1; break;
+    case SX_CONV1: a.ntaps = 1; a.tapw = 1; a.q_scale = 1; a.pad = 0; break;
+    case SX_CONVT_FWD: a.ntaps = 4; a.tapw = 2; a.q_scale = 2; a.pad = 0; break;
+    default: set_error("sx_conv_wgrad: bad mode %d", mode); return SX_ERR_INVALID;
+  }
+  a.tw_log2 = W > 8 ? 4 : (W > 4 ? 3 : 2);
+  a.TW = 1 << a.tw_log2;
+  // the transposed conv's Q tile is 4x the pixels of the P tile: keep the fp32 image inside LDS
+  a.TP = (mode == SX_CONVT_FWD && dtype == SX_F32) ? 32 : 128;
+  a.TH = a.TP / a.TW;
+  const int taph = a.ntaps / a.tapw;
+  a.LW = (a.TW - 1) * a.q_scale + a.tapw;
+  a.LH = (a.TH - 1) * a.q_scale + taph;
+  a.tiles_x = cdiv(W, a.TW);
+  a.tiles_y = cdiv(H, a.TH);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  return SX_OK;
+}
+
+template <typename T, int MI, int ITEMS>
+static int launch_wgrad(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
+  constexpr int PROW = MI * 16 * (int)sizeof(T) + WgTraits<T>::PADB;
+  constexpr int QROW = 64 * (int)sizeof(T) + WgTraits<T>::PADB;
+  const size_t smem = (size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW;
+  if (smem > 160 * 1024) { set_error("wgrad tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
+  auto kern = wgrad_kernel<T, MI, ITEMS>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad)");
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.a_tiles, p.b_tiles, p.nsplit), dim3(256), smem, st, a);
+  SX_LAUNCH_CHECK("wgrad");
+  return SX_OK;
+}
+
+template <typename T, int MI>
+static int wgrad_items(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
+  switch (p.items) {
+    case 1: return launch_wgrad<T, MI, 1>(a, p, st);
+    case 2: return launch_wgrad<T, MI, 2>(a, p, st);
+    case 3: return launch_wgrad<T, MI, 3>(a, p, st);
+    case 4: return launch_wgrad<T, MI, 4>(a, p, st);
+    case 5: return launch_wgrad<T, MI, 5>(a, p, st);
+    case 9: return launch_wgrad<T, MI, 9>(a, p, st);
+  }
+  set_error("wgrad: unexpected item count %d", p.items);
+  return SX_ERR_UNSUPPORTED;
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int64_t sx_conv_wgrad_workspace_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  // slab size does not depend on dtype; the tile count does, so size for the finer (fp32) tiling
+  if (wgrad_geom(mode, SX_F32, B, H, W, a) != SX_OK) return -1;
+  return (int64_t)wgrad_plan(mode, B, H, W, Ca, Cb, a).ws_bytes;
+}
+
+extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
+                             const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                             float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  SX_REQUIRE(P && Q && dw && workspace, "sx_conv_wgrad: null pointer");
+  SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_wgrad: bad dtype %d", dtype);
+  const int EPL = dtype == SX_BF16 ? 8 : 4;
+  if (Ca % EPL || Cb % EPL || p_ld % EPL || q_ld % EPL) {
+    set_error("sx_conv_wgrad: channel counts must be multiples of %d: Ca=%d Cb=%d p_ld=%d q_ld=%d", EPL, Ca, Cb, p_ld, q_ld);
+    return SX_ERR_UNSUPPORTED;
+  }
+  SX_REQUIRE(((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0, "sx_conv_wgrad: misaligned pointer");
+  SX_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "sx_conv_wgrad: bad output channel counts");
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));
+  if (mode == SX_CONVT_FWD) SX_REQUIRE(Hq >= 2 * H && Wq >= 2 * W, "sx_conv_wgrad: convT Q dims");
+  else SX_REQUIRE(Hq == H && Wq == W, "sx_conv_wgrad: Q dims");
+  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a);
+  SX_REQUIRE((int64_t)p.ws_bytes <= workspace_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
+             (long long)workspace_bytes, p.ws_bytes);
+  a.P = P; a.Q = Q; a.slab = (float*)workspace;
+  a.B = B; a.H = H; a.W = W; a.Hq = Hq; a.Wq = Wq; a.p_ld = p_ld; a.q_ld = q_ld;
+  a.Ca = Ca; a.Cb = Cb; a.CaPad = round_up(Ca, 16); a.CbPad = round_up(Cb, 16);
+  a.nbf = p.nbf; a.tiles_per_split = p.tiles_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dtype == SX_BF16) rc = p.MI == 4 ? wgrad_items<bf16, 4>(a, p, st) : wgrad_items<bf16, 2>(a, p, st);
+  else rc = p.MI == 4 ? wgrad_items<float, 4>(a, p, st) : wgrad_items<float, 2>(a, p, st);
+  SX_TRY(rc);
+  // PyTorch layouts: conv (a=co,b=ci): W[co][ci][tap] ; convT (a=ci,b=co): W[ci][co][tap]
+  const int64_t sa = (int64_t)Cb_out * a.ntaps, sb = a.ntaps, stp = 1;
+  const int64_t total = (int64_t)a.ntaps * Ca_out * Cb_out;
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 1024);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit,
+                     a.ntaps, Ca_out, Cb_out, a.CaPad, a.CbPad, sa, sb, stp, accumulate);
+  SX_LAUNCH_CHECK("wgrad_reduce");
+  return SX_OK;
+}

@@ -1,0 +1,30 @@
+// FiLM generator launch descriptors shared by film.hip and unet_plan.hip.
+#pragma once
+#include "sx_common.h"
+
+namespace sx {
+
+static constexpr int FILM_MAX_GEN = 16;
+static constexpr int FILM_MAX_HID = 1024;
+
+struct FilmGenDesc {
+  const float* w1; const float* b1; const float* w2; const float* b2;   // (Hf,P) (Hf) (2C,Hf) (2C)
+  float* dw1; float* db1; float* dw2; float* db2;                       // gradients (bwd)
+  float* gf; float* bf;          // [B][C] outputs
+  float* pre;                    // [B][Hf] saved pre-activation
+  const float* dgf; const float* dbf; int dg_stride;   // incoming grads: element (b,c) at (b*C + c)*dg_stride
+  float* dpre;                   // [B][Hf] scratch (bwd)
+  int C;
+};
+struct FilmArgs {
+  FilmGenDesc g[FILM_MAX_GEN];
+  int ngen, B, P, Hf;
+  const float* params;   // [B][P]
+  float* dparams;        // [B][P] (bwd, accumulated with atomics; caller zeroes)
+  int accumulate;
+};
+
+int film_forward(const FilmArgs& a, hipStream_t st);
+int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st);
+
+}  // namespace sx

@@ -1,0 +1,451 @@
+// Mask-aware weighted loss, forward + gradient, on the device (losses.py:60-213), plus the masked
+// metrics of the training loop (losses.py:226-253) and the normalizer maps (data.py:96-110,139-143,
+// 157-163,187-223).
+//
+// The loss tensors are tiny next to the network's activations (out_ch = 8 channels against 32..256),
+// so this is a short pipeline of simple bandwidth-bound kernels on planar fp32 copies rather than one
+// monolith:
+//   phase 1 (sx_loss_prepare): pooled masks / weight maps per scale and the raw denominators
+//           sum(m), sum(m*w), sum(m_g) -> `den` (9 floats).  Under data parallelism the caller
+//           all-reduces `den` between the phases: the reference's denominators are batch-global.
+//   phase 2 (sx_loss_forward_backward): numerators, the scalar loss, and d(loss)/d(pred) written
+//           back in the network's NHWC layout; also accumulates sum|p-t|*m for mae_norm.
+// Reductions: per-thread partials -> wave shuffle -> one atomicAdd per block (fp32).
+#include "sx_common.h"
+
+namespace sx {
+
+enum { PX_HUBER = 0, PX_L1 = 1, PX_MSE = 2 };
+
+__device__ __forceinline__ float px_val(int kind, float d, float beta) {
+  const float ad = fabsf(d);
+  if (kind == PX_L1) return ad;
+  if (kind == PX_MSE) return d * d;
+  return ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
+}
+__device__ __forceinline__ float px_grad(int kind, float d, float beta) {
+  if (kind == PX_L1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  if (kind == PX_MSE) return 2.f * d;
+  return d < -beta ? -1.f : (d > beta ? 1.f : d / beta);
+}
+
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(float (&v)[NV], float* dst) {
+  __shared__ float red[NV * 4];
+  block_sum<NV>(v, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) atomicAdd(dst + i, v[i]);
+  }
+}
+
+#define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// NHWC T (ld) -> planar fp32 [B][C][H][W]
+template <typename T>
+__global__ void to_planar_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int B, int C, int H, int W) {
+  const int64_t n = (int64_t)B * C * H * W;
+  GRID_STRIDE(i, n) {
+    int64_t p = i;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H); p /= H;
+    const int c = (int)(p % C);
+    const int b = (int)(p / C);
+    out[i] = to_f32(in[(((int64_t)b * H + y) * W + x) * ld + c]);
+  }
+}
+
+// planar fp32 -> NHWC T (ld, channels >= C zero-filled), scaled
+template <typename T>
+__global__ void from_planar_kernel(const float* __restrict__ in, T* __restrict__ out, int ld, int B, int C, int H, int W, float scale) {
+  const int64_t n = (int64_t)B * H * W * ld;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % ld);
+    int64_t p = i / ld;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    out[i] = from_f32<T>(c < C ? scale * in[(((int64_t)b * C + c) * H + y) * W + x] : 0.f);
+  }
+}
+
+// k x k average pooling (stride k, floor) of `planes` planes; optional threshold (> 0.5 -> 1 else 0)
+__global__ void avgpool_planar_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int h, int w, int k, int thresh) {
+  const int ho = h / k, wo = w / k;
+  const int64_t n = planes * ho * wo;
+  const float inv = 1.0f / (float)(k * k);
+  GRID_STRIDE(i, n) {
+    int64_t p = i;
+    const int x = (int)(p % wo); p /= wo;
+    const int y = (int)(p % ho);
+    const int64_t pl = p / ho;
+    const float* src = in + (pl * h + (int64_t)y * k) * w + (int64_t)x * k;
+    float s = 0.f;
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) s += src[dy * w + dx];
+    s *= inv;
+    out[i] = thresh ? (s > 0.5f ? 1.f : 0.f) : s;
+  }
+}
+
+// den[0] += sum m ; den[1] += sum m*w   over (b, pixels)
+__global__ __launch_bounds__(256) void den_kernel(const float* __restrict__ m, const float* __restrict__ w, int B, int hw, float* den, int slot_m, int slot_w) {
+  float v[2] = {0.f, 0.f};
+  const int64_t n = (int64_t)B * hw;
+  GRID_STRIDE(i, n) {
+    const float mm = m[i];
+    v[0] += mm;
+    if (w) v[1] += mm * w[i % hw];
+  }
+  __shared__ float red[8];
+  block_sum<2>(v, red);
+  if (threadIdx.x == 0) {
+    if (slot_m >= 0) atomicAdd(den + slot_m, v[0]);
+    if (slot_w >= 0 && w) atomicAdd(den + slot_w, v[1]);
+  }
+}
+
+struct BaseArgs {
+  const float* p; const float* t; const float* m; const float* w; const float* cw;
+  float* g;           // planar gradient at this scale (written, not accumulated)
+  float* num;         // num[0] += sum px*m*cw ; num[1] += sum px*m*w*cw ; num[2] += sum |p-t|*m
+  int B, C, hw;
+  int kind; float beta;
+  const float* den;   // den + 3*scale : {sum m, sum m*w, sum m_g}
+  float coef, lam_w;  // scale coefficient (1, ms_weight, ms_weight/2) and edge weight
+};
+
+__device__ __forceinline__ float cw_sum(const float* cw, int C) {
+  if (!cw) return (float)C;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += cw[c];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void base_kernel(BaseArgs a) {
+  float v[3] = {0.f, 0.f, 0.f};
+  const float scw = cw_sum(a.cw, a.C);
+  const float cb = a.coef / fmaxf(a.den[0] * scw, 1e-8f);
+  const float ce = (a.w && a.lam_w != 0.f) ? a.coef * a.lam_w / fmaxf(a.den[1] * scw, 1e-8f) : 0.f;
+  const int64_t n = (int64_t)a.B * a.C * a.hw;
+  GRID_STRIDE(i, n) {
+    const int px = (int)(i % a.hw);
+    const int64_t bc = i / a.hw;
+    const int c = (int)(bc % a.C);
+    const int b = (int)(bc / a.C);
+    const float mm = a.m[(int64_t)b * a.hw + px];
+    const float ww = a.w ? a.w[px] : 0.f;
+    const float cwc = a.cw ? a.cw[c] : 1.f;
+    const float d = a.p[i] - a.t[i];
+    const float l = px_val(a.kind, d, a.beta);
+    v[0] += l * mm * cwc;
+    v[1] += l * mm * ww * cwc;
+    v[2] += fabsf(d) * mm;
+    if (a.g) a.g[i] = px_grad(a.kind, d, a.beta) * mm * cwc * (cb + ce * ww);
+  }
+  __shared__ float red[12];
+  block_sum<3>(v, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.num + 0, v[0]);
+    atomicAdd(a.num + 1, v[1]);
+    atomicAdd(a.num + 2, v[2]);
+  }
+}
+
+__device__ __forceinline__ float at0(const float* pl, int h, int w, int y, int x) {
+  return (y >= 0 && y < h && x >= 0 && x < w) ? pl[y * w + x] : 0.f;
+}
+// 3x3 Sobel cross-correlation, zero padding (losses.py:27-39,55-56)
+__device__ __forceinline__ void sobel_at(const float* pl, int h, int w, int y, int x, float& gx, float& gy) {
+  const float a00 = at0(pl, h, w, y - 1, x - 1), a01 = at0(pl, h, w, y - 1, x), a02 = at0(pl, h, w, y - 1, x + 1);
+  const float a10 = at0(pl, h, w, y, x - 1), a12 = at0(pl, h, w, y, x + 1);
+  const float a20 = at0(pl, h, w, y + 1, x - 1), a21 = at0(pl, h, w, y + 1, x), a22 = at0(pl, h, w, y + 1, x + 1);
+  gx = (a02 - a00) + 2.f * (a12 - a10) + (a22 - a20);
+  gy = (a20 - a00) + 2.f * (a21 - a01) + (a22 - a02);
+}
+
+struct SobelArgs {
+  const float* p; const float* t; const float* m; const float* cw;   // pooled planes, thresholded mask [B][h][w]
+  float* ux; float* uy;     // d(term)/d(pgx), d(term)/d(pgy) per pooled pixel
+  float* num;               // += sum grad_px * m * cw
+  int B, C, h, w;
+  int magnitude, kind; float beta;
+  const float* den;         // den + 3*scale
+  float cgl;                // coef * lam_grad
+};
+
+__global__ __launch_bounds__(256) void sobel_fwd_kernel(SobelArgs a) {
+  float v[1] = {0.f};
+  const float cg = a.cgl / fmaxf(a.den[2] * cw_sum(a.cw, a.C), 1e-8f);
+  const int hw = a.h * a.w;
+  const int64_t n = (int64_t)a.B * a.C * hw;
+  GRID_STRIDE(i, n) {
+    const int px = (int)(i % hw);
+    const int64_t bc = i / hw;
+    const int c = (int)(bc % a.C);
+    const int b = (int)(bc / a.C);
+    const int y = px / a.w, x = px - y * a.w;
+    const float* pp = a.p + bc * hw;
+    const float* tp = a.t + bc * hw;
+    float pgx, pgy, tgx, tgy;
+    sobel_at(pp, a.h, a.w, y, x, pgx, pgy);
+    sobel_at(tp, a.h, a.w, y, x, tgx, tgy);
+    const float mm = a.m[(int64_t)b * hw + px];
+    const float cwc = a.cw ? a.cw[c] : 1.f;
+    float l, dgx, dgy;
+    if (a.magnitude) {
+      const float P = sqrtf(pgx * pgx + pgy * pgy + 1e-12f), Tm = sqrtf(tgx * tgx + tgy * tgy + 1e-12f);
+      l = px_val(a.kind, P - Tm, a.beta);
+      const float gr = px_grad(a.kind, P - Tm, a.beta);
+      dgx = gr * pgx / P;
+      dgy = gr * pgy / P;
+    } else {
+      const float dx = pgx - tgx, dy = pgy - tgy;
+      l = px_val(a.kind, dx, a.beta) + px_val(a.kind, dy, a.beta);
+      dgx = px_grad(a.kind, dx, a.beta);
+      dgy = px_grad(a.kind, dy, a.beta);
+    }
+    v[0] += l * mm * cwc;
+    if (a.ux) {
+      const float s = mm * cwc * cg;
+      a.ux[i] = dgx * s;
+      a.uy[i] = dgy * s;
+    }
+  }
+  __shared__ float red[4];
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) atomicAdd(a.num, v[0]);
+}
+
+// transposed Sobel of (ux, uy) -> gradient at pooled resolution, spread over the ds x ds window of
+// the finer plane and ADDED to g (the finer-scale gradient): g[p] += dd[q(p)] / ds^2
+__global__ void sobel_bwd_kernel(const float* __restrict__ ux, const float* __restrict__ uy, float* __restrict__ g,
+                                 int64_t planes, int h, int w, int ds, int hf, int wf) {
+  const int64_t n = planes * h * w;
+  const float inv = 1.0f / (float)(ds * ds);
+  GRID_STRIDE(i, n) {
+    int64_t p = i;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const int64_t pl = p / h;
+    const float* X = ux + pl * h * w;
+    const float* Y = uy + pl * h * w;
+    // gx(q) = sum_t kx[t] in(q + t - 1)  =>  d in(r) = sum_t kx[t] ux(r - t + 1)
+    float d = 0.f;
+    d += -1.f * at0(X, h, w, y + 1, x + 1) + 1.f * at0(X, h, w, y + 1, x - 1);
+    d += -2.f * at0(X, h, w, y, x + 1) + 2.f * at0(X, h, w, y, x - 1);
+    d += -1.f * at0(X, h, w, y - 1, x + 1) + 1.f * at0(X, h, w, y - 1, x - 1);
+    d += -1.f * at0(Y, h, w, y + 1, x + 1) - 2.f * at0(Y, h, w, y + 1, x) - 1.f * at0(Y, h, w, y + 1, x - 1);
+    d += 1.f * at0(Y, h, w, y - 1, x + 1) + 2.f * at0(Y, h, w, y - 1, x) + 1.f * at0(Y, h, w, y - 1, x - 1);
+    d *= inv;
+    float* dst = g + (pl * hf + (int64_t)y * ds) * wf + (int64_t)x * ds;
+    for (int dy = 0; dy < ds; ++dy)
+      for (int dx = 0; dx < ds; ++dx) dst[dy * wf + dx] += d;
+  }
+}
+
+// fine[p] += coarse[q(p)] / 4   (avg_pool2d(2) backward), floor semantics: trailing odd row/col untouched
+__global__ void unpool2_add_kernel(const float* __restrict__ coarse, float* __restrict__ fine, int64_t planes, int h, int w, int hf, int wf) {
+  const int64_t n = planes * h * w;
+  GRID_STRIDE(i, n) {
+    int64_t p = i;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const int64_t pl = p / h;
+    const float d = 0.25f * coarse[i];
+    float* dst = fine + (pl * hf + 2 * (int64_t)y) * wf + 2 * x;
+    dst[0] += d; dst[1] += d; dst[wf] += d; dst[wf + 1] += d;
+  }
+}
+
+struct FinalArgs {
+  const float* den; const float* num; const float* cw; int C;
+  int nscales; float lam_w, lam_grad, ms_weight; int has_w;
+  float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = sum m (scale 0)
+};
+__global__ void loss_final_kernel(FinalArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  const float scw = cw_sum(a.cw, a.C);
+  float loss = 0.f;
+  for (int s = 0; s < a.nscales; ++s) {
+    const float coef = s == 0 ? 1.f : (s == 1 ? a.ms_weight : 0.5f * a.ms_weight);
+    float L = a.num[s * 4 + 0] / fmaxf(a.den[s * 3 + 0] * scw, 1e-8f);
+    if (a.has_w && a.lam_w != 0.f) L += a.lam_w * (a.num[s * 4 + 1] / fmaxf(a.den[s * 3 + 1] * scw, 1e-8f));
+    if (a.lam_grad != 0.f) L += a.lam_grad * (a.num[s * 4 + 3] / fmaxf(a.den[s * 3 + 2] * scw, 1e-8f));
+    loss += coef * L;
+  }
+  a.out[0] = loss;
+  a.out[1] = a.num[2];
+  a.out[2] = a.den[0];
+}
+
+// ---------------------------------------------------------------- workspace layout (floats)
+struct LossLayout {
+  int ns;                     // scales (1 + multiscale)
+  int h[3], w[3];             // scale dims
+  int gds[3], gh[3], gw[3];   // grad-term pooling factor and dims per scale
+  int64_t P[3], T[3], M[3], Wm[3], G[3];     // planar copies per scale (P[0] = unpacked pred; T[0] = caller's target)
+  int64_t PG[3], TG[3], MG[3], UX[3], UY[3]; // grad-term buffers per scale
+  int64_t NUM;                // 12 floats
+  int64_t total;
+};
+
+static LossLayout loss_layout(int B, int C, int H, int W, int multiscale, int grad_ds) {
+  LossLayout L;
+  memset(&L, 0, sizeof(L));
+  L.ns = 1 + std::max(0, std::min(multiscale, 2));
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
+  L.NUM = take(16);
+  int gd = grad_ds < 1 ? 1 : grad_ds;
+  for (int s = 0; s < L.ns; ++s) {
+    L.h[s] = s == 0 ? H : L.h[s - 1] / 2;
+    L.w[s] = s == 0 ? W : L.w[s - 1] / 2;
+    L.gds[s] = s == 0 ? gd : std::max(1, gd >> s);   // max(1, grad_ds // 2), max(1, grad_ds // 4)
+    L.gh[s] = L.h[s] / L.gds[s];
+    L.gw[s] = L.w[s] / L.gds[s];
+    const int64_t n = (int64_t)B * C * L.h[s] * L.w[s];
+    const int64_t ng = (int64_t)B * C * L.gh[s] * L.gw[s];
+    L.P[s] = take(n);
+    L.T[s] = s == 0 ? -1 : take(n);
+    L.M[s] = s == 0 ? -1 : take((int64_t)B * L.h[s] * L.w[s]);
+    L.Wm[s] = s == 0 ? -1 : take((int64_t)L.h[s] * L.w[s]);
+    L.G[s] = take(n);
+    L.PG[s] = take(ng); L.TG[s] = take(ng); L.MG[s] = take((int64_t)B * L.gh[s] * L.gw[s]);
+    L.UX[s] = take(ng); L.UY[s] = take(ng);
+  }
+  L.total = off;
+  return L;
+}
+
+static inline int gsz(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
+
+static int px_kind(int k, const char* who) {
+  if (k < 0 || k > 2) { set_error("%s: unknown pixel loss kind %d", who, k); return -1; }
+  return k;
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int64_t sx_loss_workspace_bytes(int B, int C, int H, int W, int multiscale, int grad_ds) {
+  return loss_layout(B, C, H, W, multiscale, grad_ds).total * (int64_t)sizeof(float);
+}
+
+// Phase 1.  mask (B,1,H,W) fp32, w (H,W) fp32 or NULL.  Writes den[9] = per scale {sum m, sum m*w, sum m_g}.
+extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, const float* w, int multiscale,
+                               int grad_ds, float lam_grad, void* workspace, float* den, void* stream) {
+  SX_REQUIRE(mask && workspace && den, "sx_loss_prepare: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  LossLayout L = loss_layout(B, C, H, W, multiscale, grad_ds);
+  float* ws = (float*)workspace;
+  hipError_t e = hipMemsetAsync(den, 0, 9 * sizeof(float), st);
+  if (e != hipSuccess) return hip_fail(e, "memset(den)");
+  for (int s = 0; s < L.ns; ++s) {
+    if (L.h[s] < 1 || L.w[s] < 1) { set_error("sx_loss_prepare: grid %dx%d too small for multiscale=%d", H, W, multiscale); return SX_ERR_UNSUPPORTED; }
+    const float* m_s = s == 0 ? mask : ws + L.M[s];
+    const float* w_s = !w ? nullptr : (s == 0 ? w : ws + L.Wm[s]);
+    if (s > 0) {
+      const float* m_prev = s == 1 ? mask : ws + L.M[s - 1];
+      hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz((int64_t)B * L.h[s] * L.w[s])), dim3(256), 0, st, m_prev, ws + L.M[s], (int64_t)B, L.h[s - 1], L.w[s - 1], 2, 0);
+      if (w) {
+        const float* w_prev = s == 1 ? w : ws + L.Wm[s - 1];
+        hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz((int64_t)L.h[s] * L.w[s])), dim3(256), 0, st, w_prev, ws + L.Wm[s], (int64_t)1, L.h[s - 1], L.w[s - 1], 2, 0);
+      }
+    }
+    hipLaunchKernelGGL(den_kernel, dim3(gsz((int64_t)B * L.h[s] * L.w[s])), dim3(256), 0, st, m_s, w_s, B, L.h[s] * L.w[s], den, s * 3 + 0, s * 3 + 1);
+    if (lam_grad != 0.f) {
+      if (L.gh[s] < 1 || L.gw[s] < 1) { set_error("sx_loss_prepare: grid too small for grad_ds"); return SX_ERR_UNSUPPORTED; }
+      const float* mg = m_s;
+      if (L.gds[s] > 1) {
+        hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz((int64_t)B * L.gh[s] * L.gw[s])), dim3(256), 0, st, m_s, ws + L.MG[s], (int64_t)B, L.h[s], L.w[s], L.gds[s], 1);
+        mg = ws + L.MG[s];
+      }
+      hipLaunchKernelGGL(den_kernel, dim3(gsz((int64_t)B * L.gh[s] * L.gw[s])), dim3(256), 0, st, mg, (const float*)nullptr, B, L.gh[s] * L.gw[s], den, s * 3 + 2, -1);
+    }
+  }
+  SX_LAUNCH_CHECK("loss_prepare");
+  return SX_OK;
+}
+
+// Phase 2.  pred: NHWC `dtype` tensor (ld); target: planar fp32 (B,C,H,W); den from phase 1 (possibly
+// all-reduced); same workspace as phase 1.  d_pred (NHWC dtype, ld) may be NULL (evaluation).
+// out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = sum mask.  grad_scale multiplies d_pred.
+extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld,
+                                        const float* target, const float* mask, const float* w, const float* cw,
+                                        int base_kind, float huber_beta, float lam_w, float lam_grad, int grad_magnitude,
+                                        int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
+                                        void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
+                                        void* stream) {
+  SX_REQUIRE(pred && target && mask && den && workspace && out, "sx_loss_forward_backward: null pointer");
+  if (px_kind(base_kind, "sx_loss_forward_backward") < 0 || px_kind(grad_kind, "sx_loss_forward_backward") < 0) return SX_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  LossLayout L = loss_layout(B, C, H, W, multiscale, grad_ds);
+  float* ws = (float*)workspace;
+  float* num = ws + L.NUM;
+  hipError_t e = hipMemsetAsync(num, 0, 16 * sizeof(float), st);
+  if (e != hipSuccess) return hip_fail(e, "memset(num)");
+  const bool want_grad = d_pred != nullptr;
+  {
+    const int64_t n = (int64_t)B * C * H * W;
+    if (dtype == SX_BF16) hipLaunchKernelGGL(to_planar_kernel<bf16>, dim3(gsz(n)), dim3(256), 0, st, (const bf16*)pred, pred_ld, ws + L.P[0], B, C, H, W);
+    else hipLaunchKernelGGL(to_planar_kernel<float>, dim3(gsz(n)), dim3(256), 0, st, (const float*)pred, pred_ld, ws + L.P[0], B, C, H, W);
+  }
+  for (int s = 0; s < L.ns; ++s) {
+    const int hs = L.h[s], wsz = L.w[s];
+    const int64_t n = (int64_t)B * C * hs * wsz;
+    const float coef = s == 0 ? 1.f : (s == 1 ? ms_weight : 0.5f * ms_weight);
+    const float* t_s = s == 0 ? target : ws + L.T[s];
+    const float* m_s = s == 0 ? mask : ws + L.M[s];
+    const float* w_s = !w ? nullptr : (s == 0 ? w : ws + L.Wm[s]);
+    if (s > 0) {
+      hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz(n)), dim3(256), 0, st, ws + L.P[s - 1], ws + L.P[s], (int64_t)B * C, L.h[s - 1], L.w[s - 1], 2, 0);
+      const float* t_prev = s == 1 ? target : ws + L.T[s - 1];
+      hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz(n)), dim3(256), 0, st, t_prev, ws + L.T[s], (int64_t)B * C, L.h[s - 1], L.w[s - 1], 2, 0);
+    }
+    BaseArgs ba;
+    ba.p = ws + L.P[s]; ba.t = t_s; ba.m = m_s; ba.w = w_s; ba.cw = cw;
+    ba.g = want_grad ? ws + L.G[s] : nullptr;
+    ba.num = num + s * 4; ba.B = B; ba.C = C; ba.hw = hs * wsz; ba.kind = base_kind; ba.beta = huber_beta;
+    ba.den = den + s * 3; ba.coef = coef; ba.lam_w = lam_w;
+    hipLaunchKernelGGL(base_kernel, dim3(gsz(n)), dim3(256), 0, st, ba);
+    if (lam_grad != 0.f) {
+      const int gd = L.gds[s], gh = L.gh[s], gw = L.gw[s];
+      const int64_t ng = (int64_t)B * C * gh * gw;
+      const float* pg = ws + L.P[s];
+      const float* tg = t_s;
+      const float* mg = m_s;
+      if (gd > 1) {
+        hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz(ng)), dim3(256), 0, st, ws + L.P[s], ws + L.PG[s], (int64_t)B * C, hs, wsz, gd, 0);
+        hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz(ng)), dim3(256), 0, st, t_s, ws + L.TG[s], (int64_t)B * C, hs, wsz, gd, 0);
+        pg = ws + L.PG[s]; tg = ws + L.TG[s]; mg = ws + L.MG[s];   // MG built (thresholded) in phase 1
+      }
+      SobelArgs sa;
+      sa.p = pg; sa.t = tg; sa.m = mg; sa.cw = cw;
+      sa.ux = want_grad ? ws + L.UX[s] : nullptr; sa.uy = want_grad ? ws + L.UY[s] : nullptr;
+      sa.num = num + s * 4 + 3; sa.B = B; sa.C = C; sa.h = gh; sa.w = gw;
+      sa.magnitude = grad_magnitude; sa.kind = grad_kind; sa.beta = huber_beta;
+      sa.den = den + s * 3; sa.cgl = coef * lam_grad;
+      hipLaunchKernelGGL(sobel_fwd_kernel, dim3(gsz(ng)), dim3(256), 0, st, sa);
+      if (want_grad)
+        hipLaunchKernelGGL(sobel_bwd_kernel, dim3(gsz(ng)), dim3(256), 0, st, ws + L.UX[s], ws + L.UY[s], ws + L.G[s], (int64_t)B * C, gh, gw, gd, hs, wsz);
+    }
+  }
+  SX_LAUNCH_CHECK("loss scales");
+  if (want_grad) {
+    for (int s = L.ns - 1; s > 0; --s) {
+      const int64_t n = (int64_t)B * C * L.h[s] * L.w[s];
+      hipLaunchKernelGGL(unpool2_add_kernel, dim3(gsz(n)), dim3(256), 0, st, ws + L.G[s], ws + L.G[s - 1], (int64_t)B * C, L.h[s], L.w[s], L.h[s - 1], L.w[s - 1]);
+    }
+    const int64_t n = (int64_t)B * H * W * dpred_ld;
+    if (dtype == SX_BF16) hipLaunchKernelGGL(from_planar_kernel<bf16>, dim3(gsz(n)), dim3(256), 0, st, ws + L.G[0], (bf16*)d_pred, dpred_ld, B, C, H, W, grad_scale);
+    else hipLaunchKernelGGL(from_planar_kernel<float>, dim3(gsz(n)), dim3(256), 0, st, ws + L.G[0], (float*)d_pred, dpred_ld, B, C, H, W, grad_scale);
+  }
+  FinalArgs f;
+  f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = L.ns; f.lam_w = lam_w; f.lam_grad = lam_grad;
+  f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+  SX_LAUNCH_CHECK("loss_forward_backward");
+  return SX_OK;
+}

@@ -1,0 +1,256 @@
+// Small bandwidth-bound helpers around the convolutions: input packing (NCHW fp32 -> NHWC T),
+// MaxPool2d(2) forward (models.py:106,177,181) and its backward fused with the skip-connection
+// gradient add, per-channel sums (bias gradients of ConvTranspose2d / the 1x1 head,
+// models.py:127,132), global average pool (models.py:10-12) and its broadcast inverse (:32-35).
+#include "sx_common.h"
+
+namespace sx {
+
+// x: (B, Cin, H, W) fp32 with arbitrary element strides -> out NHWC T with ld channels (zero padded)
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                  T* __restrict__ out, int B, int C, int H, int W, int ld) {
+  const int64_t total = (int64_t)B * H * W * ld;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    int64_t p = i / ld;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    out[i] = from_f32<T>(c < C ? x[b * sb + c * sc + h * sh + w * sw] : 0.f);
+  }
+}
+
+// NHWC T (ld) -> (B, C, H, W) fp32 contiguous
+template <typename T>
+__global__ void unpack_output_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int B, int C, int H, int W) {
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H); p /= H;
+    const int c = (int)(p % C);
+    const int b = (int)(p / C);
+    out[i] = to_f32(in[(((int64_t)b * H + h) * W + w) * ld + c]);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, slots = C >> 3;
+  const int64_t total = (int64_t)B * Ho * Wo * slots;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % slots) << 3;
+    int64_t p = i / slots;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const T* src = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * x_ld + c0;
+    f32x8 v00 = load8(src), v01 = load8(src + x_ld), v10 = load8(src + (int64_t)W * x_ld), v11 = load8(src + (int64_t)(W + 1) * x_ld);
+    f32x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = fmaxf(fmaxf(v00.v[e], v01.v[e]), fmaxf(v10.v[e], v11.v[e]));
+    store8(y + (((int64_t)b * Ho + oy) * Wo + ox) * y_ld + c0, o);
+  }
+}
+
+// dX[b,y,x,c] = (dskip ? dskip[b,y,x,c] : 0) + (x is the first maximum of its 2x2 window ? dP[b,y/2,x/2,c] : 0)
+// One thread handles a whole 2x2 window (8 channels); odd trailing rows/cols get only the skip term.
+template <typename T>
+__global__ void maxpool_bwd_add_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dp, int dp_ld,
+                                       const T* __restrict__ dskip, int ds_ld, T* __restrict__ dx, int dx_ld,
+                                       int B, int H, int W, int C) {
+  const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1, slots = C >> 3;
+  const int64_t total = (int64_t)B * Hw * Ww * slots;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % slots) << 3;
+    int64_t p = i / slots;
+    const int wx = (int)(p % Ww); p /= Ww;
+    const int wy = (int)(p % Hw);
+    const int b = (int)(p / Hw);
+    const bool pooled = wy < Ho && wx < Wo;
+    f32x8 v[4], g;
+    int best[8];
+    if (pooled) {
+      g = load8(dp + (((int64_t)b * Ho + wy) * Wo + wx) * dp_ld + c0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v[k] = load8(x + (((int64_t)b * H + 2 * wy + (k >> 1)) * W + 2 * wx + (k & 1)) * x_ld + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int bi = 0; float bv = v[0].v[e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (v[k].v[e] > bv || (v[k].v[e] != v[k].v[e] && bv == bv)) { bv = v[k].v[e]; bi = k; }
+        best[e] = bi;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
+      if (yy >= H || xx >= W) continue;
+      const int64_t pix = ((int64_t)b * H + yy) * W + xx;
+      f32x8 o;
+      if (dskip) o = load8(dskip + pix * ds_ld + c0);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = 0.f;
+      }
+      if (pooled) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (best[e] == k) o.v[e] += g.v[e];
+      }
+      store8(dx + pix * dx_ld + c0, o);
+    }
+  }
+}
+
+// out[c] (+)= sum over b, y < Hs, x < Ws of t[b,y,x,c]   (t is B x H x W, ld)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ t, int ld, int B, int H, int W, int Hs, int Ws,
+                                                          int C, float* __restrict__ out, int pix_per_block) {
+  __shared__ float red[256];
+  const int64_t npix = (int64_t)B * Hs * Ws;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p1 = min(npix, p0 + pix_per_block);
+  const int lanes = 256 / C > 0 ? 256 / C : 1;
+  for (int cbase = 0; cbase < C; cbase += 256) {
+    const int cw = min(256, C - cbase);
+    const int ln = 256 / cw;
+    const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
+    float s = 0.f;
+    if (pl < ln)
+      for (int64_t p = p0 + pl; p < p1; p += ln) {
+        int64_t q = p;
+        const int xx = (int)(q % Ws); q /= Ws;
+        const int yy = (int)(q % Hs);
+        const int b = (int)(q / Hs);
+        s += to_f32(t[(((int64_t)b * H + yy) * W + xx) * ld + cbase + c]);
+      }
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cw) {
+      float tot = 0.f;
+      for (int l = 0; l < ln; ++l) tot += red[l * cw + threadIdx.x];
+      atomicAdd(out + cbase + threadIdx.x, tot);
+    }
+  }
+  (void)lanes;
+}
+
+// z[b][c] = mean over pixels (models.py:10-12)
+template <typename T>
+__global__ void global_avg_pool_kernel(const T* __restrict__ x, int ld, int HW, int C, float* __restrict__ z) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += to_f32(x[((int64_t)b * HW + p) * ld + c]);
+    z[(int64_t)b * C + c] = s / (float)HW;
+  }
+}
+
+__global__ void fill_zero_kernel(float* p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, per_block), cap));
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int sx_pack_input(int dtype, const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw, int B, int C,
+                             int H, int W, void* out, int out_ld, void* stream) {
+  SX_REQUIRE(x && out && out_ld >= C, "sx_pack_input: bad arguments");
+  const int64_t total = (int64_t)B * H * W * out_ld;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, x, sb, sc, sh, sw, (bf16*)out, B, C, H, W, out_ld);
+  else hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, x, sb, sc, sh, sw, (float*)out, B, C, H, W, out_ld);
+  SX_LAUNCH_CHECK("pack_input");
+  return SX_OK;
+}
+
+extern "C" int sx_unpack_output(int dtype, const void* in, int in_ld, int B, int C, int H, int W, float* out, void* stream) {
+  SX_REQUIRE(in && out && in_ld >= C, "sx_unpack_output: bad arguments");
+  const int64_t total = (int64_t)B * C * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(unpack_output_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)in, in_ld, out, B, C, H, W);
+  else hipLaunchKernelGGL(unpack_output_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)in, in_ld, out, B, C, H, W);
+  SX_LAUNCH_CHECK("unpack_output");
+  return SX_OK;
+}
+
+extern "C" int sx_maxpool2_forward(int dtype, int B, int H, int W, int C, const void* x, int x_ld, void* y, int y_ld, void* stream) {
+  SX_REQUIRE(x && y, "sx_maxpool2_forward: null pointer");
+  if (C % 8 || x_ld % 8 || y_ld % 8 || H < 2 || W < 2) { set_error("sx_maxpool2_forward: need C %% 8 == 0 and H, W >= 2 (C=%d H=%d W=%d)", C, H, W); return SX_ERR_UNSUPPORTED; }
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, x_ld, (bf16*)y, y_ld, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, x_ld, (float*)y, y_ld, B, H, W, C);
+  SX_LAUNCH_CHECK("maxpool_fwd");
+  return SX_OK;
+}
+
+extern "C" int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, const void* x, int x_ld, const void* dp,
+                                        int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream) {
+  SX_REQUIRE(x && dp && dx, "sx_maxpool2_backward_add: null pointer");
+  if (C % 8 || x_ld % 8 || dp_ld % 8 || dx_ld % 8 || (dskip && ds_ld % 8)) { set_error("sx_maxpool2_backward_add: need C %% 8 == 0"); return SX_ERR_UNSUPPORTED; }
+  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(maxpool_bwd_add_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, x_ld, (const bf16*)dp, dp_ld, (const bf16*)dskip, ds_ld, (bf16*)dx, dx_ld, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool_bwd_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, x_ld, (const float*)dp, dp_ld, (const float*)dskip, ds_ld, (float*)dx, dx_ld, B, H, W, C);
+  SX_LAUNCH_CHECK("maxpool_bwd_add");
+  return SX_OK;
+}
+
+// out must be zeroed by the caller unless accumulating on purpose.
+extern "C" int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, const void* t, int ld, float* out, void* stream) {
+  SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0, "sx_channel_sum: bad arguments");
+  const int64_t npix = (int64_t)B * Hs * Ws;
+  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, 512), 1024));
+  const int ppb = (int)cdiv64(npix, blocks);
+  blocks = (int)cdiv64(npix, ppb);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)t, ld, B, H, W, Hs, Ws, C, out, ppb);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)t, ld, B, H, W, Hs, Ws, C, out, ppb);
+  SX_LAUNCH_CHECK("channel_sum");
+  return SX_OK;
+}
+
+extern "C" int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, float* z, void* stream) {
+  SX_REQUIRE(x && z, "sx_global_avg_pool: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(global_avg_pool_kernel<bf16>, dim3(B), dim3(256), 0, st, (const bf16*)x, ld, HW, C, z);
+  else hipLaunchKernelGGL(global_avg_pool_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)x, ld, HW, C, z);
+  SX_LAUNCH_CHECK("global_avg_pool");
+  return SX_OK;
+}
+
+namespace sx {
+// zero channels [0, C) of pixels with y >= Hin or x >= Win (the F.pad strip of models.py:196-197)
+template <typename T>
+__global__ void zero_border_kernel(T* __restrict__ t, int ld, int B, int H, int W, int Hin, int Win, int C) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    if (y >= Hin || x >= Win) t[(((int64_t)b * H + y) * W + x) * ld + c] = from_f32<T>(0.f);
+  }
+}
+}  // namespace sx
+
+extern "C" int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream) {
+  SX_REQUIRE(t && Hin <= H && Win <= W, "sx_zero_border: bad arguments");
+  if (Hin == H && Win == W) return SX_OK;
+  const int64_t total = (int64_t)B * H * W * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(sx::zero_border_kernel<sx::bf16>, dim3(sx::grid_for(total)), dim3(256), 0, st, (sx::bf16*)t, ld, B, H, W, Hin, Win, C);
+  else hipLaunchKernelGGL(sx::zero_border_kernel<float>, dim3(sx::grid_for(total)), dim3(256), 0, st, (float*)t, ld, B, H, W, Hin, Win, C);
+  SX_LAUNCH_CHECK("zero_border");
+  return SX_OK;
+}

@@ -1,0 +1,331 @@
+// Bandwidth-bound kernels between the convolutions of a DoubleConv block (models.py:61-80) and the
+// FiLM modulation that follows it (models.py:152-156): GroupNorm apply + SiLU, the block output
+//   O = ((SiLU(GN(Y2)) + S) * drop) * gf + bf,
+// their backward passes (two-phase: per-(sample,channel) sums, then the elementwise gradient), and
+// the tiny parameter-gradient reductions.  GroupNorm statistics arrive as fp32 [B][G][2] (sum,
+// sum of squares) accumulated by the producing convolution's epilogue.
+//
+// Mapping: grid = (pixel chunks, B); a block works on ONE sample, so the per-channel scale/shift
+// (and FiLM / dropout factors) are computed once into LDS.  Each thread owns a fixed 8-channel
+// slot and walks pixels: 16-byte bf16 / 2x16-byte fp32 accesses, fully coalesced in NHWC.
+#include "sx_common.h"
+
+namespace sx {
+
+static constexpr int MAXC = 1024;
+
+struct ActArgs {
+  // tensors (T, NHWC)
+  const void* Y; int y_ld;        // raw conv output (pre-GN)
+  const void* S; int s_ld;        // shortcut branch (block_out fwd)
+  const void* R; int r_ld;        // saved (A2 + S) * drop  (bwd: FiLM gradient)
+  const void* dO; int do_ld;      // incoming gradient
+  void* out0; int o0_ld;          // fwd: A or O     ; bwd: dY
+  void* out1; int o1_ld;          // fwd: R (opt)    ; bwd: dR (opt)
+  // per-sample / per-channel fp32
+  const float* stats;             // [B][G][2]
+  const float* gamma; const float* beta;   // [C]
+  const float* gf; const float* bf;        // [B][C] FiLM (1+gamma), beta   (nullable)
+  const float* drop;                       // [B][C] dropout factors        (nullable)
+  float* sums;                             // [B][C][4] backward sums
+  int B, HW, C, G;
+  float eps;
+  int pix_per_block;
+};
+
+// per-channel GN coefficients of sample b into LDS: n_hat = y * rs[c] - mr[c]; z = n_hat * ga[c] + be[c]
+__device__ __forceinline__ void gn_coeffs(const ActArgs& a, int b, float* rs, float* mr) {
+  const int cpg = a.C / a.G;
+  const float inv_n = 1.0f / ((float)cpg * (float)a.HW);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const float* st = a.stats + ((int64_t)b * a.G + c / cpg) * 2;
+    const float mean = st[0] * inv_n;
+    const float var = fmaxf(st[1] * inv_n - mean * mean, 0.f);
+    const float r = rsqrtf(var + a.eps);
+    rs[c] = r;
+    mr[c] = mean * r;
+  }
+}
+
+// ---------------------------------------------------------------- forward
+// MODE 0: out0 = silu(gn(Y))                      (first GN of the block)
+// MODE 1: R = (silu(gn(Y)) + S) * drop ; out0 = R * gf + bf ; out1 = R (if non-null)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_fwd_kernel(ActArgs a) {
+  __shared__ float sc[MAXC], sh[MAXC];
+  __shared__ float fg[MODE ? MAXC : 1], fb[MODE ? MAXC : 1], dr[MODE ? MAXC : 1];
+  const int b = blockIdx.y;
+  gn_coeffs(a, b, sc, sh);
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const float r = sc[c], m = sh[c], ga = a.gamma[c];
+    sc[c] = r * ga;
+    sh[c] = a.beta[c] - m * ga;
+    if (MODE) {
+      fg[c] = a.gf ? a.gf[(int64_t)b * a.C + c] : 1.f;
+      fb[c] = a.bf ? a.bf[(int64_t)b * a.C + c] : 0.f;
+      dr[c] = a.drop ? a.drop[(int64_t)b * a.C + c] : 1.f;
+    }
+  }
+  __syncthreads();
+  const int slots = a.C >> 3;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
+  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
+  const int64_t n_items = (p1 - p0) * slots;
+  const T* Y = reinterpret_cast<const T*>(a.Y);
+  const T* S = reinterpret_cast<const T*>(a.S);
+  T* O0 = reinterpret_cast<T*>(a.out0);
+  T* O1 = reinterpret_cast<T*>(a.out1);
+  for (int64_t it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const int64_t pix = (int64_t)b * a.HW + p0 + it / slots;
+    const int c0 = (int)(it % slots) << 3;
+    f32x8 y = load8(Y + pix * a.y_ld + c0);
+    f32x8 o;
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.v[e] = siluf_(y.v[e] * sc[c0 + e] + sh[c0 + e]);
+      store8(O0 + pix * a.o0_ld + c0, o);
+    } else {
+      f32x8 s = load8(S + pix * a.s_ld + c0), r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r.v[e] = (siluf_(y.v[e] * sc[c0 + e] + sh[c0 + e]) + s.v[e]) * dr[c0 + e];
+        o.v[e] = r.v[e] * fg[c0 + e] + fb[c0 + e];
+      }
+      store8(O0 + pix * a.o0_ld + c0, o);
+      if (O1) store8(O1 + pix * a.o1_ld + c0, r);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward, phase 1
+// sums[b][c] += { sum dz*n_hat, sum dz, sum dO*R, sum dO }   (last two only for MODE 1)
+//   dz = dO * gf * drop * silu'(z)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
+  __shared__ float rs[MAXC], mr[MAXC], ga[MAXC], be[MAXC], fac[MAXC];
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.y;
+  gn_coeffs(a, b, rs, mr);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    ga[c] = a.gamma[c];
+    be[c] = a.beta[c];
+    float f = 1.f;
+    if (MODE) {
+      if (a.gf) f *= a.gf[(int64_t)b * a.C + c];
+      if (a.drop) f *= a.drop[(int64_t)b * a.C + c];
+    }
+    fac[c] = f;
+  }
+  __syncthreads();
+  const int slots = a.C >> 3;
+  const int lanes = 256 / slots;                 // pixel lanes per block (slots <= 256)
+  const int slot = threadIdx.x % slots, pl = threadIdx.x / slots;
+  const int c0 = slot << 3;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
+  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
+  const T* Y = reinterpret_cast<const T*>(a.Y);
+  const T* R = reinterpret_cast<const T*>(a.R);
+  const T* dO = reinterpret_cast<const T*>(a.dO);
+  constexpr int NS = MODE ? 4 : 2;
+  float acc[NS][8];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+  if (pl < lanes) {
+    for (int64_t p = p0 + pl; p < p1; p += lanes) {
+      const int64_t pix = (int64_t)b * a.HW + p;
+      f32x8 y = load8(Y + pix * a.y_ld + c0);
+      f32x8 g = load8(dO + pix * a.do_ld + c0);
+      f32x8 r;
+      if (MODE) r = load8(R + pix * a.r_ld + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float nh = y.v[e] * rs[c0 + e] - mr[c0 + e];
+        const float z = nh * ga[c0 + e] + be[c0 + e];
+        const float dz = g.v[e] * fac[c0 + e] * dsiluf_(z);
+        acc[0][e] += dz * nh;
+        acc[1][e] += dz;
+        if (MODE) { acc[2][e] += g.v[e] * r.v[e]; acc[3][e] += g.v[e]; }
+      }
+    }
+  }
+  // reduce over the pixel lanes that share a slot
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[k][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+      const int sl = c >> 3, e = c & 7;
+      float s = 0.f;
+      for (int l = 0; l < lanes; ++l) s += red[(l * slots + sl) * 8 + e];
+      atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, s);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward, phase 2
+// dY = rstd * (gamma*dz - mean_g(gamma*dz) - n_hat * mean_g(gamma*dz*n_hat)) ; dR = dO*gf*drop (optional)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
+  __shared__ float rs[MAXC], mr[MAXC], ga[MAXC], be[MAXC], fac[MAXC], m1[MAXC], m2[MAXC];
+  const int b = blockIdx.y;
+  gn_coeffs(a, b, rs, mr);
+  const int cpg = a.C / a.G;
+  const float inv_n = 1.0f / ((float)cpg * (float)a.HW);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    ga[c] = a.gamma[c];
+    be[c] = a.beta[c];
+    float f = 1.f;
+    if (MODE) {
+      if (a.gf) f *= a.gf[(int64_t)b * a.C + c];
+      if (a.drop) f *= a.drop[(int64_t)b * a.C + c];
+    }
+    fac[c] = f;
+    const int gbase = (c / cpg) * cpg;
+    float t1 = 0.f, t2 = 0.f;
+    for (int cc = gbase; cc < gbase + cpg; ++cc) {
+      const float* s = a.sums + ((int64_t)b * a.C + cc) * 4;
+      const float gm = a.gamma[cc];
+      t2 += gm * s[0];
+      t1 += gm * s[1];
+    }
+    m1[c] = t1 * inv_n;
+    m2[c] = t2 * inv_n;
+  }
+  __syncthreads();
+  const int slots = a.C >> 3;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
+  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
+  const int64_t n_items = (p1 - p0) * slots;
+  const T* Y = reinterpret_cast<const T*>(a.Y);
+  const T* dO = reinterpret_cast<const T*>(a.dO);
+  T* dY = reinterpret_cast<T*>(a.out0);
+  T* dR = reinterpret_cast<T*>(a.out1);
+  for (int64_t it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const int64_t pix = (int64_t)b * a.HW + p0 + it / slots;
+    const int c0 = (int)(it % slots) << 3;
+    f32x8 y = load8(Y + pix * a.y_ld + c0);
+    f32x8 g = load8(dO + pix * a.do_ld + c0);
+    f32x8 o, r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const float nh = y.v[e] * rs[c] - mr[c];
+      const float z = nh * ga[c] + be[c];
+      const float da = g.v[e] * fac[c];
+      const float dz = da * dsiluf_(z);
+      r.v[e] = da;
+      o.v[e] = rs[c] * (ga[c] * dz - m1[c] - nh * m2[c]);
+    }
+    store8(dY + pix * a.o0_ld + c0, o);
+    if (MODE && dR) store8(dR + pix * a.o1_ld + c0, r);
+  }
+}
+
+// dgamma[c] (+)= sum_b sums[b][c][0] ; dbeta[c] (+)= sum_b sums[b][c][1]
+__global__ void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float g = 0.f, bt = 0.f;
+  for (int b = 0; b < B; ++b) {
+    g += sums[((int64_t)b * C + c) * 4 + 0];
+    bt += sums[((int64_t)b * C + c) * 4 + 1];
+  }
+  dgamma[c] = accumulate ? dgamma[c] + g : g;
+  dbeta[c] = accumulate ? dbeta[c] + bt : bt;
+}
+
+static int act_check(const ActArgs& a, const char* who) {
+  if (a.C % 8 || a.C > MAXC || a.G <= 0 || a.C % a.G) {
+    set_error("%s: unsupported channel count C=%d groups=%d (need C %% 8 == 0, C <= %d)", who, a.C, a.G, MAXC);
+    return SX_ERR_UNSUPPORTED;
+  }
+  if (a.B <= 0 || a.HW <= 0) { set_error("%s: empty problem", who); return SX_ERR_INVALID; }
+  return SX_OK;
+}
+
+static dim3 act_grid(ActArgs& a) {
+  // ~2048 blocks in total, at least 64 pixels per block
+  int chunks = std::max(1, std::min(cdiv(a.HW, 64), cdiv(2048, a.B)));
+  a.pix_per_block = cdiv(a.HW, chunks);
+  chunks = cdiv(a.HW, a.pix_per_block);
+  return dim3(chunks, a.B);
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+#define SX_DISPATCH_T(dtype, KERN, MODE, grid, st, args)                                    \
+  do {                                                                                      \
+    if ((dtype) == SX_BF16) hipLaunchKernelGGL((KERN<bf16, MODE>), grid, dim3(256), 0, st, args); \
+    else hipLaunchKernelGGL((KERN<float, MODE>), grid, dim3(256), 0, st, args);             \
+  } while (0)
+
+extern "C" int sx_gn_silu_forward(int dtype, int B, int HW, int C, int groups, float eps, const void* y, int y_ld,
+                                  const float* stats, const float* gamma, const float* beta, void* out, int out_ld,
+                                  void* stream) {
+  SX_REQUIRE(y && stats && gamma && beta && out, "sx_gn_silu_forward: null pointer");
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out0 = out; a.o0_ld = out_ld;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
+  SX_TRY(act_check(a, "sx_gn_silu_forward"));
+  dim3 grid = act_grid(a);
+  SX_DISPATCH_T(dtype, act_fwd_kernel, 0, grid, (hipStream_t)stream, a);
+  SX_LAUNCH_CHECK("gn_silu_forward");
+  return SX_OK;
+}
+
+extern "C" int sx_block_out_forward(int dtype, int B, int HW, int C, int groups, float eps, const void* y2, int y_ld,
+                                    const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                                    const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                                    void* r_out, int r_ld, void* stream) {
+  SX_REQUIRE(y2 && stats && gamma && beta && s && out, "sx_block_out_forward: null pointer");
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Y = y2; a.y_ld = y_ld; a.S = s; a.s_ld = s_ld; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.gf = film_g; a.bf = film_b; a.drop = drop; a.out0 = out; a.o0_ld = out_ld; a.out1 = r_out; a.o1_ld = r_ld;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
+  SX_TRY(act_check(a, "sx_block_out_forward"));
+  dim3 grid = act_grid(a);
+  SX_DISPATCH_T(dtype, act_fwd_kernel, 1, grid, (hipStream_t)stream, a);
+  SX_LAUNCH_CHECK("block_out_forward");
+  return SX_OK;
+}
+
+// mode 0: gradient through A = silu(gn(Y));  mode 1: through the block output (FiLM, dropout, residual).
+// sums must be zeroed by the caller ([B][C][4] fp32).
+extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
+                                   int y_ld, const float* stats, const float* gamma, const float* beta,
+                                   const void* d_out, int do_ld, const void* r, int r_ld, const float* film_g,
+                                   const float* drop, float* sums, void* dy, int dy_ld, void* d_r, int dr_ld,
+                                   float* dgamma, float* dbeta, int accumulate, void* stream) {
+  SX_REQUIRE(y && stats && gamma && beta && d_out && sums && dy, "sx_gn_silu_backward: null pointer");
+  SX_REQUIRE(mode == 0 || (mode == 1 && r), "sx_gn_silu_backward: mode 1 needs the saved block sum R");
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dO = d_out; a.do_ld = do_ld;
+  a.R = r; a.r_ld = r_ld; a.gf = film_g; a.drop = drop; a.sums = sums; a.out0 = dy; a.o0_ld = dy_ld;
+  a.out1 = d_r; a.o1_ld = dr_ld;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
+  SX_TRY(act_check(a, "sx_gn_silu_backward"));
+  dim3 grid = act_grid(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid, st, a); }
+  else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid, st, a); }
+  SX_LAUNCH_CHECK("gn_bwd_reduce");
+  if (mode) { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 1, grid, st, a); }
+  else { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 0, grid, st, a); }
+  SX_LAUNCH_CHECK("gn_bwd_apply");
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, dgamma, dbeta, B, C, accumulate);
+    SX_LAUNCH_CHECK("gn_param_grad");
+  }
+  return SX_OK;
+}

@@ -1,0 +1,98 @@
+// Optimizer step of the training loop (train.py:82,226-233): global gradient norm,
+// clip_grad_norm_ (scale = min(1, max_norm / (norm + 1e-6))) and decoupled-weight-decay Adam
+// (torch.optim.AdamW, amsgrad off), fused over ONE flat fp32 parameter arena that is also the
+// gradient all-reduce bucket.  28 B of HBM traffic per parameter (read p,g,m,v; write p,m,v).
+#include "sx_common.h"
+
+namespace sx {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  float v[1] = {0.f};
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(g + i * 4);
+    v[0] += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[n4 * 4 + threadIdx.x]; v[0] += x * x; }
+  __shared__ float red[4];
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) atomicAdd(out, v[0]);
+}
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
+  float max_norm; const float* gnorm_sq; float grad_mul;
+  float* gnorm_out;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float gmul) {
+  g *= gmul;
+  p *= 1.0f - a.lr * a.wd;
+  m = a.beta1 * m + (1.0f - a.beta1) * g;
+  v = a.beta2 * v + (1.0f - a.beta2) * g * g;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p -= (a.lr / a.bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  float gmul = a.grad_mul;
+  if (a.gnorm_sq) {
+    const float norm = sqrtf(a.gnorm_sq[0]) * fabsf(a.grad_mul);
+    if (a.max_norm > 0.f) gmul *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
+    if (a.gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) a.gnorm_out[0] = norm;
+  }
+  const int64_t n4 = a.n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 p = *reinterpret_cast<f32x4*>(a.p + i * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
+    f32x4 m = *reinterpret_cast<f32x4*>(a.m + i * 4);
+    f32x4 v = *reinterpret_cast<f32x4*>(a.v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float pe = p[e], me = m[e], ve = v[e]; adam_one(pe, g[e], me, ve, a, gmul); p[e] = pe; m[e] = me; v[e] = ve; }
+    *reinterpret_cast<f32x4*>(a.p + i * 4) = p;
+    *reinterpret_cast<f32x4*>(a.m + i * 4) = m;
+    *reinterpret_cast<f32x4*>(a.v + i * 4) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a, gmul);
+  }
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+// out[0] += sum g^2 (caller zeroes out)
+extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
+  SX_REQUIRE(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq: bad arguments");
+  if (n == 0) return SX_OK;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 1024));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  SX_LAUNCH_CHECK("grad_sumsq");
+  return SX_OK;
+}
+
+// One AdamW step over a flat arena.  step is the 1-based step count.  If gnorm_sq != NULL the
+// gradients are first scaled by min(1, max_norm / (sqrt(gnorm_sq) * |grad_mul| + 1e-6)) (max_norm <= 0:
+// no clipping); grad_mul is a plain multiplier (e.g. 1/world_size, or 1/loss_scale).
+// gnorm_out (nullable) receives the pre-clip norm.
+extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float max_norm,
+                             const float* gnorm_sq, float grad_mul, float* gnorm_out, void* stream) {
+  SX_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "sx_adamw_step: bad arguments");
+  SX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+             "sx_adamw_step: arenas must be 16-byte aligned");
+  if (n == 0) return SX_OK;
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.max_norm = max_norm; a.gnorm_sq = gnorm_sq; a.grad_mul = grad_mul; a.gnorm_out = gnorm_out;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 2048));
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  SX_LAUNCH_CHECK("adamw_step");
+  return SX_OK;
+}

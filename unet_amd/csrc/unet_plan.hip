@@ -1,0 +1,509 @@
+// Whole-network orchestration of the FiLM-conditioned residual U-Net (models.py:98-213) on top of
+// the kernels of this library: UNet.encode / UNet.decode and their backward passes, each ONE call
+// from the host language.  Pure host code: it computes where every tensor lives inside the
+// caller-provided workspace and enqueues kernels on the caller's stream.
+//
+// HBM layout (NHWC, activation dtype T): per encoder level l one "cat" buffer [B,Hl,Wl,2*Cl] whose
+// upper channel half IS the skip tensor (written by the encoder's block epilogue) and whose lower
+// half is written by the decoder's transposed convolution -- torch.cat (models.py:200) costs nothing.
+// Every DoubleConv block keeps Y1 (raw conv1), A1, Y2 (raw conv2), S (shortcut), R (pre-FiLM sum),
+// and its GroupNorm statistics for backward.
+#include "sx_common.h"
+#include "film.h"
+#include <vector>
+
+namespace sx {
+
+static constexpr float GN_EPS = 1e-5f;
+
+struct BlockBuf {   // byte offsets into the workspace
+  int64_t Y1, A1, Y2, S, R, O;      // O: block output (skip half of a cat buffer for encoders)
+  int o_ld;
+  int64_t st1, st2;                 // GN statistics [B][G][2] fp32
+  int64_t gf, bf, pre, dpre;        // FiLM: [B][C] fp32 x2, [B][Hf] fp32 x2
+  int64_t dO, dY, dA1, dR;          // gradients (T)
+  int64_t sums1, sums2;             // [B][C][4] fp32
+  int64_t dX; int dx_ld;            // gradient w.r.t. the block input
+  int Cin, Cin_real, C, H, W, G;
+  int64_t in; int in_ld;            // block input
+  // packed weights (byte offsets into wpack)
+  int64_t w1f, w1d, w2f, w2d, wsf, wsd;
+  int pidx;                         // index of net.0.weight in the parameter table
+  int film_pidx;                    // index of film net.0.weight, -1 if none
+};
+
+struct Plan {
+  sx_unet_desc d;
+  int esz;                    // sizeof(T)
+  int in_pad, out_pad;
+  int depth;
+  int C[8], H[8], W[8];       // per level 0..depth
+  std::vector<BlockBuf> blk;  // encoders 0..depth-1, bot (index depth), decoders (index depth+1+j)
+  int64_t X0, cat[8], dcat[8], Pool[8], pred, dpred, dparams;
+  int64_t stats_begin, stats_end, sums_begin, sums_end;
+  int64_t wg_ws; int64_t wg_ws_bytes;
+  // convT / head packed weights and parameter indices
+  int64_t upf[8], upb[8]; int up_pidx[8];
+  int64_t headf, headd, head_bias; int out_pidx;
+  int64_t ws_bytes, wpack_bytes;
+  int nparams;
+};
+
+static int build_plan(const sx_unet_desc* dp, Plan& p) {
+  if (!dp) { set_error("null descriptor"); return SX_ERR_INVALID; }
+  const sx_unet_desc& d = *dp;
+  p.d = d;
+  if (d.dtype != SX_F32 && d.dtype != SX_BF16) { set_error("unet: bad dtype %d", d.dtype); return SX_ERR_INVALID; }
+  if (d.depth < 1 || d.depth > 6) { set_error("unet: depth %d outside 1..6", d.depth); return SX_ERR_UNSUPPORTED; }
+  if (d.base < 8 || d.base % 8) { set_error("unet: base=%d must be a positive multiple of 8 for the HIP path", d.base); return SX_ERR_UNSUPPORTED; }
+  if (d.groups_gn < 1 || d.in_ch < 1 || d.out_ch < 1 || d.B < 1) { set_error("unet: bad sizes"); return SX_ERR_INVALID; }
+  if (d.use_film && (d.P < 1 || d.P > 64 || d.film_hidden < 1 || d.film_hidden > 1024)) { set_error("unet: FiLM sizes unsupported (P=%d hidden=%d)", d.P, d.film_hidden); return SX_ERR_UNSUPPORTED; }
+  if ((d.H >> d.depth) < 1 || (d.W >> d.depth) < 1) { set_error("unet: grid %dx%d too small for depth %d", d.H, d.W, d.depth); return SX_ERR_UNSUPPORTED; }
+  if (d.base << d.depth > 1024) { set_error("unet: bottleneck width %d > 1024", d.base << d.depth); return SX_ERR_UNSUPPORTED; }
+  p.esz = (int)dtype_size(d.dtype);
+  p.depth = d.depth;
+  p.in_pad = round_up(d.in_ch, 8);
+  p.out_pad = round_up(d.out_ch, 8);
+  for (int l = 0; l <= d.depth; ++l) {
+    p.C[l] = d.base << l;
+    p.H[l] = l == 0 ? d.H : p.H[l - 1] / 2;
+    p.W[l] = l == 0 ? d.W : p.W[l - 1] / 2;
+    const int g = std::min(d.groups_gn, p.C[l]);
+    if (p.C[l] % g) { set_error("unet: GroupNorm groups %d do not divide %d channels", g, p.C[l]); return SX_ERR_INVALID; }
+  }
+  const int B = d.B, D = d.depth;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { int64_t o = off; off += (int64_t)align_up((size_t)bytes, 256); return o; };
+  auto act = [&](int l, int C) { return take((int64_t)B * p.H[l] * p.W[l] * C * p.esz); };
+
+  p.X0 = act(0, p.in_pad);
+  for (int l = 0; l < D; ++l) {
+    p.cat[l] = act(l, 2 * p.C[l]);
+    p.dcat[l] = act(l, 2 * p.C[l]);
+    p.Pool[l] = act(l + 1, p.C[l]);
+  }
+  p.pred = act(0, p.out_pad);
+  p.dpred = act(0, p.out_pad);
+  p.dparams = take((int64_t)B * std::max(1, d.P) * 4);
+
+  p.blk.assign(2 * D + 1, BlockBuf());
+  // parameter-table indices
+  const int n_blocks = 2 * D + 1;
+  const int idx_bot = 7 * D, idx_up0 = 7 * (D + 1), idx_dec0 = idx_up0 + 2 * D, idx_out = idx_dec0 + 7 * D;
+  const int idx_film0 = idx_out + 2;
+  p.out_pidx = idx_out;
+  p.nparams = idx_film0 + (d.P > 0 ? 4 * n_blocks : 0);
+
+  for (int k = 0; k < n_blocks; ++k) {
+    BlockBuf& b = p.blk[k];
+    int l;
+    if (k < D) {            // encoder level k
+      l = k;
+      b.Cin_real = k == 0 ? d.in_ch : p.C[k - 1];
+      b.Cin = k == 0 ? p.in_pad : p.C[k - 1];
+      b.in = k == 0 ? p.X0 : p.Pool[k - 1];
+      b.in_ld = b.Cin;
+      b.pidx = 7 * k;
+      b.film_pidx = d.P > 0 ? idx_film0 + 4 * k : -1;
+    } else if (k == D) {    // bottleneck
+      l = D;
+      b.Cin_real = b.Cin = p.C[D - 1];
+      b.in = p.Pool[D - 1];
+      b.in_ld = b.Cin;
+      b.pidx = idx_bot;
+      b.film_pidx = d.P > 0 ? idx_film0 + 4 * D : -1;
+    } else {                // decoder j at level D-1-j
+      const int j = k - D - 1;
+      l = D - 1 - j;
+      b.Cin_real = b.Cin = 2 * p.C[l];
+      b.in = p.cat[l];
+      b.in_ld = 2 * p.C[l];
+      b.pidx = idx_dec0 + 7 * j;
+      b.film_pidx = d.P > 0 ? idx_film0 + 4 * (D + 1 + j) : -1;
+    }
+    b.C = p.C[l]; b.H = p.H[l]; b.W = p.W[l];
+    b.G = std::min(d.groups_gn, b.C);
+    b.Y1 = act(l, b.C); b.A1 = act(l, b.C); b.Y2 = act(l, b.C); b.S = act(l, b.C); b.R = act(l, b.C);
+    if (k < D) { b.O = p.cat[l] + (int64_t)b.C * p.esz; b.o_ld = 2 * b.C; }
+    else { b.O = act(l, b.C); b.o_ld = b.C; }
+    b.dO = act(l, b.C); b.dY = act(l, b.C); b.dA1 = act(l, b.C); b.dR = act(l, b.C);
+    b.gf = take((int64_t)B * b.C * 4); b.bf = take((int64_t)B * b.C * 4);
+    b.pre = take((int64_t)B * std::max(1, d.film_hidden) * 4); b.dpre = take((int64_t)B * std::max(1, d.film_hidden) * 4);
+  }
+  // gradient w.r.t. block inputs
+  for (int k = 0; k < n_blocks; ++k) {
+    BlockBuf& b = p.blk[k];
+    if (k == 0) { b.dX = -1; b.dx_ld = 0; }
+    else if (k <= D) { b.dX = take((int64_t)B * b.H * b.W * b.Cin * p.esz); b.dx_ld = b.Cin; }   // = d(pool_{k-1})
+    else { const int l = D - 1 - (k - D - 1); b.dX = p.dcat[l]; b.dx_ld = 2 * p.C[l]; }
+  }
+  // statistics and backward sums: contiguous so one memset clears them
+  p.stats_begin = off;
+  for (auto& b : p.blk) { b.st1 = take((int64_t)B * b.G * 2 * 4); b.st2 = take((int64_t)B * b.G * 2 * 4); }
+  p.stats_end = off;
+  p.sums_begin = off;
+  for (auto& b : p.blk) { b.sums1 = take((int64_t)B * b.C * 4 * 4); b.sums2 = take((int64_t)B * b.C * 4 * 4); }
+  p.sums_end = off;
+  // wgrad slabs: the largest any layer needs
+  int64_t wgmax = 0;
+  for (auto& b : p.blk) {
+    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV3, B, b.H, b.W, b.C, b.C));
+    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV3, B, b.H, b.W, b.C, b.Cin));
+    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV1, B, b.H, b.W, b.C, b.Cin));
+  }
+  for (int j = 0; j < D; ++j) {
+    const int l = D - 1 - j;
+    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l]));
+  }
+  wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV1, B, d.H, d.W, p.out_pad, p.C[0]));
+  p.wg_ws_bytes = wgmax;
+  p.wg_ws = take(wgmax);
+  p.ws_bytes = off;
+
+  // ---- packed weights
+  int64_t woff = 0;
+  auto wtake = [&](int mode, int rows, int k) {
+    int64_t o = woff;
+    woff += (int64_t)align_up((size_t)(sx_packed_weight_elems(mode, d.dtype, rows, k) * p.esz), 256);
+    return o;
+  };
+  for (auto& b : p.blk) {
+    b.w1f = wtake(SX_CONV3, b.C, b.Cin_real); b.w1d = wtake(SX_CONV3, b.Cin_real, b.C);
+    b.w2f = wtake(SX_CONV3, b.C, b.C);        b.w2d = wtake(SX_CONV3, b.C, b.C);
+    b.wsf = wtake(SX_CONV1, b.C, b.Cin_real); b.wsd = wtake(SX_CONV1, b.Cin_real, b.C);
+  }
+  for (int j = 0; j < D; ++j) {
+    const int l = D - 1 - j;
+    p.upf[j] = wtake(SX_CONVT_FWD, p.C[l], p.C[l + 1]);
+    p.upb[j] = wtake(SX_CONVT_BWD, p.C[l + 1], p.C[l]);
+    p.up_pidx[j] = idx_up0 + 2 * j;
+  }
+  p.headf = wtake(SX_CONV1, p.out_pad, p.C[0]);
+  p.headd = wtake(SX_CONV1, p.C[0], p.out_pad);
+  p.head_bias = woff; woff += 256;
+  p.wpack_bytes = woff;
+  return SX_OK;
+}
+
+static inline char* at(void* base, int64_t off) { return (char*)base + off; }
+static inline const char* at(const void* base, int64_t off) { return (const char*)base + off; }
+
+__global__ void pad_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n, int npad) {
+  const int i = threadIdx.x;
+  if (i < npad) out[i] = i < n ? b[i] : 0.f;
+}
+
+// ---------------------------------------------------------------- FiLM helpers
+static void film_fill(const Plan& p, int k, const float* const* params, float* const* grads, void* ws, FilmGenDesc& g) {
+  const BlockBuf& b = p.blk[k];
+  g.w1 = params[b.film_pidx]; g.b1 = params[b.film_pidx + 1]; g.w2 = params[b.film_pidx + 2]; g.b2 = params[b.film_pidx + 3];
+  if (grads) { g.dw1 = grads[b.film_pidx]; g.db1 = grads[b.film_pidx + 1]; g.dw2 = grads[b.film_pidx + 2]; g.db2 = grads[b.film_pidx + 3]; }
+  else g.dw1 = g.db1 = g.dw2 = g.db2 = nullptr;
+  g.gf = (float*)at(ws, b.gf); g.bf = (float*)at(ws, b.bf); g.pre = (float*)at(ws, b.pre); g.dpre = (float*)at(ws, b.dpre);
+  const float* sums = (const float*)at(ws, b.sums2);
+  g.dgf = sums + 2; g.dbf = sums + 3; g.dg_stride = 4;
+  g.C = b.C;
+}
+
+static int film_run_forward(const Plan& p, int k0, int k1, const float* const* params, void* ws, const float* film_params, hipStream_t st) {
+  FilmArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
+  for (int k = k0; k < k1; ++k) film_fill(p, k, params, nullptr, ws, fa.g[k - k0]);
+  return film_forward(fa, st);
+}
+
+static int film_run_backward(const Plan& p, int k0, int k1, const float* const* params, float* const* grads, void* ws,
+                             const float* film_params, int flags, hipStream_t st) {
+  FilmArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
+  fa.dparams = (float*)at(ws, p.dparams);
+  fa.accumulate = (flags & SX_BWD_ACCUMULATE) ? 1 : 0;
+  const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
+  for (int k = k0; k < k1; ++k) film_fill(p, k, params, wg ? grads : nullptr, ws, fa.g[k - k0]);
+  return film_backward(fa, wg, st);
+}
+
+// ---------------------------------------------------------------- one DoubleConv block
+static int block_forward(const Plan& p, int k, const float* const* params, const void* wpack, void* ws, bool film,
+                         const float* drop, hipStream_t st) {
+  const BlockBuf& b = p.blk[k];
+  const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
+  const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
+  const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
+  SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.w1f), nullptr,
+                         at(ws, b.Y1), b.C, b.H, b.W, 0, (float*)at(ws, b.st1), b.G, st));
+  SX_TRY(sx_gn_silu_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1, at(ws, b.A1), b.C, st));
+  SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.A1), b.C, b.H, b.W, at(wpack, b.w2f), nullptr,
+                         at(ws, b.Y2), b.C, b.H, b.W, 0, (float*)at(ws, b.st2), b.G, st));
+  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
+                         at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, st));
+  const bool keep_r = film || drop;
+  SX_TRY(sx_block_out_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2, at(ws, b.S), b.C,
+                              film ? (const float*)at(ws, b.gf) : nullptr, film ? (const float*)at(ws, b.bf) : nullptr, drop,
+                              at(ws, b.O), b.o_ld, keep_r ? at(ws, b.R) : nullptr, b.C, st));
+  return SX_OK;
+}
+
+// d_out is read from b.dO.  Writes parameter gradients (if wg) and the input gradient into b.dX (if need_dx).
+static int block_backward(const Plan& p, int k, const float* const* params, float* const* grads, const void* wpack, void* ws,
+                          bool film, const float* drop, bool need_dx, int flags, hipStream_t st) {
+  const BlockBuf& b = p.blk[k];
+  const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
+  const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
+  const int acc = (flags & SX_BWD_ACCUMULATE) ? 1 : 0;
+  const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
+  const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
+  const bool keep_r = film || drop;
+  const void* Rsrc = keep_r ? at(ws, b.R) : at(ws, b.O);
+  const int r_ld = keep_r ? b.C : b.o_ld;
+  // through FiLM / dropout / residual / SiLU / GN2
+  SX_TRY(sx_gn_silu_backward(dt, 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
+                             at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
+                             (float*)at(ws, b.sums2), at(ws, b.dY), b.C, keep_r ? at(ws, b.dR) : nullptr, b.C,
+                             wg ? grads[b.pidx + 4] : nullptr, wg ? grads[b.pidx + 5] : nullptr, acc, st));
+  const void* dR = keep_r ? at(ws, b.dR) : at(ws, b.dO);
+  if (wg)
+    SX_TRY(sx_conv_wgrad(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W,
+                         grads[b.pidx + 3], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
+  SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w2d), nullptr,
+                         at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
+  // through SiLU / GN1 (dY buffer is reused for dY1)
+  SX_TRY(sx_gn_silu_backward(dt, 0, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
+                             at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY), b.C,
+                             nullptr, 0, wg ? grads[b.pidx + 1] : nullptr, wg ? grads[b.pidx + 2] : nullptr, acc, st));
+  if (wg) {
+    SX_TRY(sx_conv_wgrad(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY), b.C, at(ws, b.in), b.in_ld, b.H, b.W,
+                         grads[b.pidx + 0], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
+    SX_TRY(sx_conv_wgrad(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, b.C, at(ws, b.in), b.in_ld, b.H, b.W,
+                         grads[b.pidx + 6], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
+  }
+  if (need_dx) {
+    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
+                           at(ws, b.dX), b.dx_ld, b.H, b.W, 0, nullptr, 0, st));
+    SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, dR, b.C, b.H, b.W, at(wpack, b.wsd), nullptr,
+                           at(ws, b.dX), b.dx_ld, b.H, b.W, 1, nullptr, 0, st));
+  }
+  return SX_OK;
+}
+
+static int check_tables(const Plan& p, const float* const* params, const void* wpack, void* ws) {
+  if (!params || !wpack || !ws) { set_error("unet: null params / wpack / workspace"); return SX_ERR_INVALID; }
+  for (int i = 0; i < p.nparams; ++i)
+    if (!params[i]) { set_error("unet: parameter %d is null", i); return SX_ERR_INVALID; }
+  if ((uintptr_t)ws % 256 || (uintptr_t)wpack % 256) { set_error("unet: workspace / wpack must be 256-byte aligned"); return SX_ERR_INVALID; }
+  return SX_OK;
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" int sx_unet_num_params(const sx_unet_desc* d) {
+  Plan p;
+  if (build_plan(d, p) != SX_OK) return -1;
+  return p.nparams;
+}
+extern "C" int64_t sx_unet_wpack_bytes(const sx_unet_desc* d) {
+  Plan p;
+  if (build_plan(d, p) != SX_OK) return -1;
+  return p.wpack_bytes;
+}
+extern "C" int64_t sx_unet_workspace_bytes(const sx_unet_desc* d) {
+  Plan p;
+  if (build_plan(d, p) != SX_OK) return -1;
+  return p.ws_bytes;
+}
+
+extern "C" int sx_unet_view(const sx_unet_desc* d, int which, int index, sx_view* out) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_REQUIRE(out, "sx_unet_view: null output");
+  const int D = p.depth;
+  auto set = [&](int64_t off, int ld, int C, int l) { out->offset_bytes = off; out->ld = ld; out->C = C; out->H = p.H[l]; out->W = p.W[l]; };
+  switch (which) {
+    case SX_T_INPUT: set(p.X0, p.in_pad, d->in_ch, 0); break;
+    case SX_T_SKIP:
+      SX_REQUIRE(index >= 0 && index < D, "sx_unet_view: skip index %d", index);
+      set(p.blk[index].O, 2 * p.C[index], p.C[index], index); break;
+    case SX_T_BOTTLENECK: set(p.blk[D].O, p.C[D], p.C[D], D); break;
+    case SX_T_PRED: set(p.pred, p.out_pad, d->out_ch, 0); break;
+    case SX_T_DPRED: set(p.dpred, p.out_pad, d->out_ch, 0); break;
+    case SX_T_DSKIP:
+      SX_REQUIRE(index >= 0 && index < D, "sx_unet_view: dskip index %d", index);
+      set(p.dcat[index] + (int64_t)p.C[index] * p.esz, 2 * p.C[index], p.C[index], index); break;
+    case SX_T_DBOTTLENECK: set(p.blk[D].dO, p.C[D], p.C[D], D); break;
+    case SX_T_FILM_DPARAMS: out->offset_bytes = p.dparams; out->ld = d->P; out->C = d->P; out->H = 1; out->W = 1; break;
+    default: set_error("sx_unet_view: unknown tensor %d", which); return SX_ERR_INVALID;
+  }
+  return SX_OK;
+}
+
+extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* params, void* wpack, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_REQUIRE(params && wpack, "sx_unet_pack_weights: null pointer");
+  const int dt = d->dtype;
+  for (auto& b : p.blk) {
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 0, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1f), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 1, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1d), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 0, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2f), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 1, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2d), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 0, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsf), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 1, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsd), stream));
+  }
+  for (int j = 0; j < p.depth; ++j) {
+    const int l = p.depth - 1 - j;
+    // ConvTranspose2d weight is (Cin = C[l+1], Cout = C[l], 2, 2)
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONVT_FWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upf[j]), stream));
+    SX_TRY(sx_pack_conv_weight(dt, SX_CONVT_BWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upb[j]), stream));
+  }
+  SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 0, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headf), stream));
+  SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 1, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headd), stream));
+  SX_REQUIRE(p.out_pad <= 64, "sx_unet_pack_weights: out_ch %d too large", d->out_ch);
+  hipLaunchKernelGGL(pad_bias_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params[p.out_pidx + 1], (float*)at(wpack, p.head_bias), d->out_ch, p.out_pad);
+  SX_LAUNCH_CHECK("pad_bias");
+  return SX_OK;
+}
+
+extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
+                              const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                              const float* film_params, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_TRY(check_tables(p, params, wpack, ws));
+  SX_REQUIRE(x, "sx_unet_encode: null input");
+  const bool film = d->use_film != 0;
+  SX_REQUIRE(!film || film_params, "sx_unet_encode: FiLM requested without params");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = d->dtype, B = d->B, D = p.depth;
+  // clear the encoder's GN statistics (blocks 0..D are laid out first)
+  {
+    const int64_t b0 = p.blk[0].st1, b1 = p.blk[D + 1].st1;
+    hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(b1 - b0), st);
+    if (e != hipSuccess) return hip_fail(e, "memset(stats)");
+  }
+  SX_TRY(sx_pack_input(dt, x, sb, sc, sh, sw, B, d->in_ch, d->H, d->W, at(ws, p.X0), p.in_pad, stream));
+  if (film) SX_TRY(film_run_forward(p, 0, D + 1, params, ws, film_params, st));
+  for (int k = 0; k <= D; ++k) {
+    SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st));
+    if (k < D)
+      SX_TRY(sx_maxpool2_forward(dt, B, p.H[k], p.W[k], p.C[k], at(ws, p.blk[k].O), 2 * p.C[k], at(ws, p.Pool[k]), p.C[k], stream));
+  }
+  return SX_OK;
+}
+
+extern "C" int sx_unet_decode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
+                              const float* film_params, const float* const* drop, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_TRY(check_tables(p, params, wpack, ws));
+  const bool film = d->use_film != 0;
+  SX_REQUIRE(!film || film_params, "sx_unet_decode: FiLM requested without params");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = d->dtype, B = d->B, D = p.depth;
+  {
+    const int64_t b0 = p.blk[D + 1].st1;
+    hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(p.stats_end - b0), st);
+    if (e != hipSuccess) return hip_fail(e, "memset(stats)");
+  }
+  if (film) SX_TRY(film_run_forward(p, D + 1, 2 * D + 1, params, ws, film_params, st));
+  for (int j = 0; j < D; ++j) {
+    const int l = D - 1 - j, k = D + 1 + j;
+    const BlockBuf& prev = p.blk[k - 1];   // bottleneck for j = 0, else decoder j-1
+    // h = up(h): ConvTranspose2d into channels [0, C_l) of the cat buffer; zero the F.pad strip
+    SX_TRY(sx_zero_border(dt, B, p.H[l], p.W[l], 2 * p.H[l + 1], 2 * p.W[l + 1], p.C[l], at(ws, p.cat[l]), 2 * p.C[l], stream));
+    SX_TRY(sx_conv_forward(dt, SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld, p.H[l + 1], p.W[l + 1],
+                           at(wpack, p.upf[j]), params[p.up_pidx[j] + 1], at(ws, p.cat[l]), 2 * p.C[l], p.H[l], p.W[l], 0, nullptr, 0, stream));
+    SX_TRY(block_forward(p, k, params, wpack, ws, film, drop ? drop[j] : nullptr, st));
+  }
+  const BlockBuf& last = p.blk[2 * D];
+  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.C[0], p.out_pad, at(ws, last.O), last.o_ld, d->H, d->W, at(wpack, p.headf),
+                         (const float*)at(wpack, p.head_bias), at(ws, p.pred), p.out_pad, d->H, d->W, 0, nullptr, 0, stream));
+  return SX_OK;
+}
+
+extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const* params, float* const* grads,
+                                       const void* wpack, void* ws, const float* film_params,
+                                       const float* const* drop, int flags, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_TRY(check_tables(p, params, wpack, ws));
+  const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
+  const int acc = (flags & SX_BWD_ACCUMULATE) ? 1 : 0;
+  SX_REQUIRE(!wg || grads, "sx_unet_decode_backward: weight gradients requested without a gradient table");
+  const bool film = d->use_film != 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = d->dtype, B = d->B, D = p.depth;
+  {
+    const int64_t s0 = p.blk[D + 1].sums1;
+    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(p.sums_end - s0), st);
+    if (e != hipSuccess) return hip_fail(e, "memset(sums)");
+    if (flags & SX_BWD_ZERO_DPARAMS) {
+      e = hipMemsetAsync(at(ws, p.dparams), 0, (size_t)B * std::max(1, d->P) * 4, st);
+      if (e != hipSuccess) return hip_fail(e, "memset(dparams)");
+    }
+  }
+  // head
+  const BlockBuf& last = p.blk[2 * D];
+  if (wg) {
+    SX_TRY(sx_conv_wgrad(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
+                         at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
+    float* db = grads[p.out_pidx + 1];
+    if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)d->out_ch * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
+    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, d->out_ch, at(ws, p.dpred), p.out_pad, db, stream));
+  }
+  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], at(ws, p.dpred), p.out_pad, d->H, d->W, at(wpack, p.headd),
+                         nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
+  for (int j = D - 1; j >= 0; --j) {
+    const int l = D - 1 - j, k = D + 1 + j;
+    SX_TRY(block_backward(p, k, params, grads, wpack, ws, film, drop ? drop[j] : nullptr, true, flags, st));
+    const BlockBuf& prev = p.blk[k - 1];
+    const int Hs = 2 * p.H[l + 1], Ws = 2 * p.W[l + 1];
+    if (wg) {
+      float* db = grads[p.up_pidx[j] + 1];
+      if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)p.C[l] * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
+      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
+      SX_TRY(sx_conv_wgrad(dt, SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
+                           at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
+    }
+    // gradient w.r.t. the transposed conv's input = d_out of the previous block
+    SX_TRY(sx_conv_forward(dt, SX_CONVT_BWD, B, p.H[l + 1], p.W[l + 1], p.C[l], p.C[l + 1], at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l],
+                           at(wpack, p.upb[j]), nullptr, at(ws, prev.dO), p.C[l + 1], p.H[l + 1], p.W[l + 1], 0, nullptr, 0, stream));
+  }
+  if (film) SX_TRY(film_run_backward(p, D + 1, 2 * D + 1, params, grads, ws, film_params, flags, st));
+  return SX_OK;
+}
+
+extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const* params, float* const* grads,
+                                       const void* wpack, void* ws, const float* film_params, int flags, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  SX_TRY(check_tables(p, params, wpack, ws));
+  const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
+  SX_REQUIRE(!wg || grads, "sx_unet_encode_backward: weight gradients requested without a gradient table");
+  const bool film = d->use_film != 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = d->dtype, B = d->B, D = p.depth;
+  {
+    const int64_t s0 = p.blk[0].sums1, s1 = p.blk[D + 1].sums1;
+    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
+    if (e != hipSuccess) return hip_fail(e, "memset(sums)");
+    if (flags & SX_BWD_ZERO_DPARAMS) {
+      e = hipMemsetAsync(at(ws, p.dparams), 0, (size_t)B * std::max(1, d->P) * 4, st);
+      if (e != hipSuccess) return hip_fail(e, "memset(dparams)");
+    }
+  }
+  // bottleneck: d_out already in blk[D].dO ; skips' gradients in dcat[l] upper halves
+  SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, st));
+  for (int l = D - 1; l >= 0; --l) {
+    const BlockBuf& b = p.blk[l];
+    const BlockBuf& nxt = p.blk[l + 1];   // its dX is d(pool_l)
+    SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
+                                    at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
+    SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, st));
+  }
+  if (film) SX_TRY(film_run_backward(p, 0, D + 1, params, grads, ws, film_params, flags, st));
+  return SX_OK;
+}
