@@ -1,0 +1,91 @@
+"""Data-parallel helpers: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" in the CPU tests).  The reference is single-device; what DP must preserve is
+its batch-GLOBAL loss denominators (solpex/losses.py:77-79):
+
+    1. every rank computes its local raw denominators  sum(m), sum(m*w), sum(m_g)       (sx_loss_prepare)
+    2. all-reduce(SUM) those <= 9 floats                                                (this module)
+    3. every rank forms numerators / gradients with the GLOBAL denominators            (sx_loss_forward_backward)
+    4. all-reduce(SUM) the flat gradient arena (no division by world size), then clip + AdamW, identical on
+       every rank.
+With identical masks on every sample this reduces to ordinary gradient averaging.
+"""
+from __future__ import annotations
+
+import os
+import torch
+import torch.distributed as dist
+
+
+def is_active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world, local_rank).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    r = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(r)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=r, world_size=world)
+    return r, world, local
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce_sum(t, async_op=False):
+    """In-place SUM all-reduce of a tensor (no-op when there is one rank)."""
+    if not is_active():
+        return _Done() if async_op else t
+    h = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+    return h if async_op else t
+
+
+def shard_range(n, r=None, w=None):
+    """Contiguous [begin, end) share of n independent units for rank r of w (embarrassingly parallel paths)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    per, rem = divmod(n, w)
+    b = r * per + min(r, rem)
+    return b, b + per + (1 if r < rem else 0)
+
+
+def gather_rows(local, n_total):
+    """All-gather row blocks of unequal length (shard_range layout) into an (n_total, ...) tensor on every rank."""
+    if not is_active():
+        return local
+    w = world_size()
+    sizes = [shard_range(n_total, r, w) for r in range(w)]
+    mx = max(e - b for b, e in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:e - b] for o, (b, e) in zip(outs, sizes)], dim=0)
+
+
+def global_loss_protocol(local_den, local_terms_fn):
+    """The 4-step protocol above in host terms (used by the CPU gloo tests with the oracle as the
+    compute): all-reduce the raw denominators, then let the caller build loss / gradients from them."""
+    den = local_den.clone()
+    all_reduce_sum(den)
+    return local_terms_fn(den)
