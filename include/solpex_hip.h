@@ -128,7 +128,8 @@ int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, f
  *   sx_unpack_output   : NHWC dtype -> (B,C,H,W) fp32 contiguous
  *   sx_maxpool2_forward: nn.MaxPool2d(2) (models.py:106,177,181)
  *   sx_maxpool2_backward_add: dx = dskip (optional) + max-pool backward of dp (first maximum wins, as ATen)
- *   sx_channel_sum     : out[c] += sum_{b, y<Hs, x<Ws} t[b,y,x,c]  (bias gradients; caller zeroes out)
+ *   sx_channel_sum     : out[c] += sum_{b, y<Hs, x<Ws} t[b,y,x,c] for c < C_out <= C (bias gradients; C % 8 == 0;
+ *                        caller zeroes out)
  *   sx_global_avg_pool : bottleneck_to_z (models.py:10-12)
  *   sx_zero_border     : zero channels [0,C) of pixels outside Hin x Win (F.pad strip, models.py:196-197)
  * --------------------------------------------------------------------------------------------- */
@@ -138,7 +139,7 @@ int sx_unpack_output(int dtype, const void* in, int in_ld, int B, int C, int H, 
 int sx_maxpool2_forward(int dtype, int B, int H, int W, int C, const void* x, int x_ld, void* y, int y_ld, void* stream);
 int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, const void* x, int x_ld, const void* dp,
                              int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream);
-int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, const void* t, int ld, float* out, void* stream);
+int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, void* stream);
 int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, float* z, void* stream);
 int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream);
 

@@ -189,7 +189,7 @@ def test_full_size_properties_cfg2_shape():
         full = model(x, params=p).float()
         parts = torch.cat([model(x[i:i + 8], params=p[i:i + 8]).float() for i in range(0, 64, 8)])
     assert torch.isfinite(full).all()
-    assert rel_err(full.cpu(), parts.cpu()) < 2e-3
+    assert rel_err(full.cpu(), parts.cpu()) < 1e-2
     model.train()
     pred = model(x, params=p)
     loss = masked_weighted_loss(pred, y, torch.zeros_like(m), lam_grad=0.1, lam_w=0.5, grad_ds=2)

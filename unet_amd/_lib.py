@@ -52,7 +52,7 @@ SIGNATURES = {
     "sx_unpack_output": (_i, [_i, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sx_maxpool2_forward": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "sx_maxpool2_backward_add": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
-    "sx_channel_sum": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "sx_channel_sum": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "sx_global_avg_pool": (_i, [_i, _i, _i, _i, _p, _i, _p, _p]),
     "sx_zero_border": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "sx_loss_workspace_bytes": (_l, [_i] * 6),

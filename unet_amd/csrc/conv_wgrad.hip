@@ -180,21 +180,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 }
 
 // out[a*sa + b*sb + tap*st] (+)= sum_s slab[s][tap][a][b]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntaps,
-                                    int Ca, int Cb, int CaPad, int CbPad, int64_t sa, int64_t sb, int64_t st,
-                                    int accumulate) {
-  const int64_t total = (int64_t)ntaps * Ca * Cb;
+// Block = 16 consecutive b (one 64-byte segment of a slab row) x 16 split lanes; the lanes' partial sums are
+// combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntaps,
+                                                           int Ca, int Cb, int CaPad, int CbPad, int64_t sa, int64_t sb, int64_t st,
+                                                           int accumulate) {
+  __shared__ float red[16][17];
+  const int bchunks = (Cb + 15) >> 4;
+  const int64_t nrows = (int64_t)ntaps * Ca;
   const int64_t slab_sz = (int64_t)ntaps * CaPad * CbPad;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i % Cb);
-    const int64_t t2 = i / Cb;
-    const int aa = (int)(t2 % Ca);
-    const int tap = (int)(t2 / Ca);
-    const float* src = slab + ((int64_t)tap * CaPad + aa) * CbPad + b;
+  const int e = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  for (int64_t blk = blockIdx.x; blk < nrows * bchunks; blk += gridDim.x) {
+    const int bc = (int)(blk % bchunks);
+    const int64_t row = blk / bchunks;
+    const int aa = (int)(row % Ca), tap = (int)(row / Ca);
+    const int b = bc * 16 + e;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += src[k * slab_sz];
-    float* dst = out + aa * sa + b * sb + tap * st;
-    *dst = accumulate ? (*dst + s) : s;
+    if (b < Cb) {
+      const float* src = slab + ((int64_t)tap * CaPad + aa) * CbPad + b;
+      for (int k = lane; k < nsplit; k += 16) s += src[k * slab_sz];
+    }
+    red[lane][e] = s;
+    __syncthreads();
+    if (lane == 0 && b < Cb) {
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) t += red[l][e];
+      float* dst = out + aa * sa + b * sb + tap * st;
+      *dst = accumulate ? (*dst + t) : t;
+    }
+    __syncthreads();
   }
 }
 
@@ -210,7 +225,7 @@ static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const Wg
   p.items = cdiv(g.ntaps * p.nbf, 4);
   const int ntiles = B * g.tiles_x * g.tiles_y;
   const size_t slab1 = (size_t)g.ntaps * CaPad * CbPad * sizeof(float);
-  int ns = std::max(1, 1024 / (p.a_tiles * p.b_tiles));
+  int ns = std::max(1, 512 / (p.a_tiles * p.b_tiles));
   ns = std::min(ns, ntiles);
   ns = std::min<int>(ns, std::max<size_t>(1, ((size_t)32 << 20) / slab1));
   p.tiles_per_split = cdiv(ntiles, ns);
@@ -316,8 +331,7 @@ extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, i
   SX_TRY(rc);
   // PyTorch layouts: conv (a=co,b=ci): W[co][ci][tap] ; convT (a=ci,b=co): W[ci][co][tap]
   const int64_t sa = (int64_t)Cb_out * a.ntaps, sb = a.ntaps, stp = 1;
-  const int64_t total = (int64_t)a.ntaps * Ca_out * Cb_out;
-  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 1024);
+  const int blocks = (int)std::min<int64_t>((int64_t)a.ntaps * Ca_out * cdiv(Cb_out, 16), 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit,
                      a.ntaps, Ca_out, Cb_out, a.CaPad, a.CbPad, sa, sb, stp, accumulate);
   SX_LAUNCH_CHECK("wgrad_reduce");

@@ -104,38 +104,38 @@ __global__ void maxpool_bwd_add_kernel(const T* __restrict__ x, int x_ld, const 
   }
 }
 
-// out[c] (+)= sum over b, y < Hs, x < Ws of t[b,y,x,c]   (t is B x H x W, ld)
+// out[c] (+)= sum over b, y < Hs, x < Ws of t[b,y,x,c]   (t is B x H x W, ld).  C % 8 == 0, C <= 2048:
+// each thread owns an 8-channel slot and walks pixels (16-byte loads), lanes combine through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ t, int ld, int B, int H, int W, int Hs, int Ws,
-                                                          int C, float* __restrict__ out, int pix_per_block) {
-  __shared__ float red[256];
+                                                          int C, int C_out, float* __restrict__ out, int pix_per_block) {
+  __shared__ float red[256 * 8];
   const int64_t npix = (int64_t)B * Hs * Ws;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
   const int64_t p1 = min(npix, p0 + pix_per_block);
-  const int lanes = 256 / C > 0 ? 256 / C : 1;
-  for (int cbase = 0; cbase < C; cbase += 256) {
-    const int cw = min(256, C - cbase);
-    const int ln = 256 / cw;
-    const int c = threadIdx.x % cw, pl = threadIdx.x / cw;
-    float s = 0.f;
-    if (pl < ln)
-      for (int64_t p = p0 + pl; p < p1; p += ln) {
-        int64_t q = p;
-        const int xx = (int)(q % Ws); q /= Ws;
-        const int yy = (int)(q % Hs);
-        const int b = (int)(q / Hs);
-        s += to_f32(t[(((int64_t)b * H + yy) * W + xx) * ld + cbase + c]);
-      }
-    __syncthreads();
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < cw) {
-      float tot = 0.f;
-      for (int l = 0; l < ln; ++l) tot += red[l * cw + threadIdx.x];
-      atomicAdd(out + cbase + threadIdx.x, tot);
+  const int slots = C >> 3, lanes = 256 / slots;
+  const int slot = threadIdx.x % slots, pl = threadIdx.x / slots;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (pl < lanes)
+    for (int64_t p = p0 + pl; p < p1; p += lanes) {
+      int64_t q = p;
+      const int xx = (int)(q % Ws); q /= Ws;
+      const int yy = (int)(q % Hs);
+      const int b = (int)(q / Hs);
+      const f32x8 v = load8(t + (((int64_t)b * H + yy) * W + xx) * ld + (slot << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v.v[e];
     }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C_out; c += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[(l * slots + (c >> 3)) * 8 + (c & 7)];
+    atomicAdd(out + c, s);
   }
-  (void)lanes;
 }
 
 // z[b][c] = mean over pixels (models.py:10-12)
@@ -206,15 +206,16 @@ extern "C" int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, c
 }
 
 // out must be zeroed by the caller unless accumulating on purpose.
-extern "C" int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, const void* t, int ld, float* out, void* stream) {
-  SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0, "sx_channel_sum: bad arguments");
+extern "C" int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, void* stream) {
+  SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0 && C_out > 0 && C_out <= C, "sx_channel_sum: bad arguments");
+  if (C % 8 || ld % 8 || C > 2048) { set_error("sx_channel_sum: need C %% 8 == 0 and C <= 2048 (C=%d ld=%d)", C, ld); return SX_ERR_UNSUPPORTED; }
   const int64_t npix = (int64_t)B * Hs * Ws;
   int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, 512), 1024));
   const int ppb = (int)cdiv64(npix, blocks);
   blocks = (int)cdiv64(npix, ppb);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SX_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)t, ld, B, H, W, Hs, Ws, C, out, ppb);
-  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)t, ld, B, H, W, Hs, Ws, C, out, ppb);
+  if (dtype == SX_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb);
   SX_LAUNCH_CHECK("channel_sum");
   return SX_OK;
 }

@@ -227,17 +227,28 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
 }
 
 // dgamma[c] (+)= sum_b sums[b][c][0] ; dbeta[c] (+)= sum_b sums[b][c][1]
-__global__ void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C,
-                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 64 channels x 4 batch lanes (fixed-order LDS combine)
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C,
+                                                            int accumulate) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float g = 0.f, bt = 0.f;
-  for (int b = 0; b < B; ++b) {
-    g += sums[((int64_t)b * C + c) * 4 + 0];
-    bt += sums[((int64_t)b * C + c) * 4 + 1];
+  if (c < C)
+    for (int b = bl; b < B; b += 4) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(sums + ((int64_t)b * C + c) * 4);
+      g += v[0];
+      bt += v[1];
+    }
+  red[0][bl][cl] = g;
+  red[1][bl][cl] = bt;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    g = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    bt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    dgamma[c] = accumulate ? dgamma[c] + g : g;
+    dbeta[c] = accumulate ? dbeta[c] + bt : bt;
   }
-  dgamma[c] = accumulate ? dgamma[c] + g : g;
-  dbeta[c] = accumulate ? dbeta[c] + bt : bt;
 }
 
 static int act_check(const ActArgs& a, const char* who) {
@@ -324,7 +335,7 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   else { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 0, grid, st, a); }
   SX_LAUNCH_CHECK("gn_bwd_apply");
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, dgamma, dbeta, B, C, accumulate);
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, sums, dgamma, dbeta, B, C, accumulate);
     SX_LAUNCH_CHECK("gn_param_grad");
   }
   return SX_OK;

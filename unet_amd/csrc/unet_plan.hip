@@ -452,7 +452,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
                          at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
     float* db = grads[p.out_pidx + 1];
     if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)d->out_ch * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
-    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, d->out_ch, at(ws, p.dpred), p.out_pad, db, stream));
+    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, db, stream));
   }
   SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], at(ws, p.dpred), p.out_pad, d->H, d->W, at(wpack, p.headd),
                          nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
@@ -464,7 +464,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     if (wg) {
       float* db = grads[p.up_pidx[j] + 1];
       if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)p.C[l] * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
-      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
+      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
       SX_TRY(sx_conv_wgrad(dt, SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
                            at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
     }
