@@ -1,0 +1,159 @@
+"""GPU: the training / inference loops (train_unet, load_checkpoint, predict_fields, TrainEngine) against the
+reference's own 2-epoch history (golden) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import cfg_from_golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+
+class _ListDS(torch.utils.data.Dataset):
+    def __init__(self, bt):
+        self.bt = bt
+
+    def __len__(self):
+        return self.bt["x"].shape[0]
+
+    def __getitem__(self, i):
+        return {k: v[i] for k, v in self.bt.items()}
+
+
+def _norm():
+    from unet_amd import data as D
+    keys, norms = [f"c{i}" for i in range(8)], {}
+    for i, k in enumerate(keys):
+        if i % 3 == 0:
+            n = D.MaskedLogStandardizer(eps=1.0); n.mu, n.sigma = torch.tensor(1.0 + 0.1 * i), torch.tensor(0.8)
+        elif i % 3 == 1:
+            n = D.MaskedSymLogStandardizer(scale=5.0); n.mu, n.sigma = torch.tensor(0.1 * i), torch.tensor(1.2)
+        else:
+            n = D.MaskedLinearStandardizer(); n.mu, n.sigma = torch.tensor(0.5), torch.tensor(2.0)
+        norms[k] = n
+    return D.MultiChannelNormalizer(keys, norms)
+
+
+def test_train_unet_two_epochs_match_reference_history(golden, tmp_path):
+    """Same loaders, weights and kwargs as tools/make_golden.py::train_case (fp32): history, final weights,
+    checkpoint keys; then the deploy-style round trip load_checkpoint -> predict_fields."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from oracle import unet_ref, norm_ref
+    from unet_amd.models import UNet
+    from unet_amd.train import train_unet
+    from unet_amd.predict import load_checkpoint, predict_fields, predict_fields_batch
+    from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8
+    g = golden("train_history.npz")
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=4)
+    tr = make_batch(6, 16, 8, seed=100, jitter_masks=True)
+    va = make_batch(4, 16, 8, seed=101, jitter_masks=True)
+    tl = torch.utils.data.DataLoader(_ListDS(tr), batch_size=2, shuffle=False)
+    vl = torch.utils.data.DataLoader(_ListDS(va), batch_size=2, shuffle=False)
+    norm = _norm()
+
+    def mk(in_ch, out_ch):
+        m = UNet(in_ch=in_ch, out_ch=out_ch, base=8, P=5, film_hidden=16, depth=2)
+        m.load_state_dict(sd)
+        return m
+    path = str(tmp_path / "best.pt")
+    model, hist = train_unet(tl, vl, norm, 1, "cuda", out_ch=8, lam_grad=0.1, lam_w=0.5, epochs=2, base=8, model_cls=mk,
+                             P=5, film_hidden=16, depth=2, save_path=path, multiscale=1, lr_init=2e-3, amp=False,
+                             lam_grad_warmup_start=0, lam_grad_warmup_end=1, channel_weights=CHANNEL_WEIGHTS_8,
+                             param_scaler=(np.zeros(5, np.float32), np.ones(5, np.float32)))
+    for k in ("tr_mse", "tr_maeN", "va_mse", "va_maeN", "va_mae_eV", "va_rmse_eV", "lr"):
+        np.testing.assert_allclose(np.asarray(hist[k]), g["hist_" + k], rtol=3e-4, err_msg=k)
+    fin = model.state_dict()
+    for k in ("out.weight", "encoders.0.net.0.weight", "film_bot.net.2.bias"):
+        assert rel_err(fin[k].cpu(), g["final::" + k]) < 1e-3, k
+    ck = torch.load(path, weights_only=False)
+    assert sorted(ck.keys()) == [str(s) for s in g["ckpt_keys"]]
+    assert int(ck["epoch"]) == int(g["ckpt_epoch"])
+    assert set(ck["opt"]["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # deploy-style check (scripts/run_conditional_unet_pipeline.py:332-343)
+    # NB the reference's load_checkpoint does not forward `depth` (solpex/predict.py:76-77): a depth-2 checkpoint
+    # cannot be loaded by it, nor (by design of the drop-in) by ours -- same RuntimeError from load_state_dict.
+    with pytest.raises(RuntimeError):
+        load_checkpoint(path, "cuda")
+    from unet_amd.predict import _norm_from_ckpt
+    norm2 = _norm_from_ckpt(ck["norm"])
+    m3 = mk(1, 8).cuda()
+    m3.load_state_dict(ck["model"])
+    mask = va["mask"][0, 0].numpy()
+    prm = va["params"][0].numpy()
+    out = predict_fields(m3, norm2, mask, prm)
+    assert out.shape == (8, 16, 8) and out.dtype == np.float32 and np.isfinite(out).all()
+    sdc = {k: v.cpu() for k, v in ck["model"].items()}
+    z = unet_ref.unet_forward(sdc, cfg, va["x"][:1], va["params"][:1])
+    specs = []
+    for i in range(8):
+        kind = int(g["norm_kinds"][i])
+        specs.append(norm_ref.NormSpec({0: 0, 1: 2, 2: 1}[kind], *( (1.0 + 0.1 * i, 0.8, 1.0, 1.0) if kind == 0 else
+                                                                     (0.1 * i, 1.2, 1e-12, 5.0) if kind == 1 else (0.5, 2.0, 1e-12, 1.0))))
+    ref = norm_ref.norm_inverse(specs, z.detach(), va["mask"][:1])[0].numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    outs = predict_fields_batch(m3, norm2, va["mask"][:, 0].numpy(), va["params"].numpy())
+    np.testing.assert_allclose(outs[0], out, rtol=1e-4, atol=1e-4 * np.abs(out).max())
+
+
+def test_engine_step_equals_autograd_path_and_oracle_adamw():
+    """TrainEngine.train_step (direct C calls, flat arenas) == autograd path + oracle AdamW/clip on the same batch."""
+    from oracle import optim_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.losses import masked_weighted_loss, edge_weights
+    from unet_amd.synth import make_batch
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=6)
+    bt = {k: v.cuda() for k, v in make_batch(4, 16, 16, seed=3, jitter_masks=True).items()}
+    w = torch.from_numpy(edge_weights(bt["mask"][0, 0].cpu().numpy()))
+    opts = dict(lam_w=0.5, lam_grad=0.1, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1", multiscale=1,
+                ms_weight=0.5, grad_ds=2)
+    a = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2); a.load_state_dict(sd); a = a.cuda().train()
+    b = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2); b.load_state_dict(sd); b = b.cuda().train()
+    loss = masked_weighted_loss(a(bt["x"], params=bt["params"]), bt["y"], bt["mask"], w=w.cuda(), **opts)
+    loss.backward()
+    eng = TrainEngine(b, dtype=torch.float32, lr=1e-2, weight_decay=1e-4, clip_grad=0.5, w_map=w, loss_opts=opts)
+    out = eng.train_step(bt["x"], bt["y"], bt["mask"], bt["params"], lam_grad=0.1, step_now=False)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(loss)) < 1e-5 * abs(float(loss))
+    ga = {k: p.grad.clone() for k, p in a.named_parameters()}
+    for k, p in b.named_parameters():
+        assert rel_err(p.grad.cpu(), ga[k].cpu()) < 1e-4, k
+    names = list(ga)
+    clipped, total = optim_ref.clip_grad_norm([ga[k].cpu() for k in names], 0.5)
+    eng.optimizer_step(1e-2)
+    torch.cuda.synchronize()
+    assert abs(float(eng.gnorm) - float(total)) < 1e-4 * float(total)
+    pb = dict(b.named_parameters())
+    for k, g in zip(names, clipped):
+        pn, _, _ = optim_ref.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-2, weight_decay=1e-4)
+        assert rel_err(pb[k].detach().cpu(), pn) < 1e-5, k
+
+
+def test_load_checkpoint_depth3_round_trip(tmp_path):
+    """depth-3 checkpoint (what every reference caller trains): save via train_unet, load_checkpoint, predict."""
+    from unet_amd.train import train_unet
+    from unet_amd.predict import load_checkpoint, predict_fields, predict_te
+    from unet_amd.synth import make_batch
+    tr = make_batch(4, 32, 16, seed=7, jitter_masks=True)
+    tl = torch.utils.data.DataLoader(_ListDS(tr), batch_size=2, shuffle=False)
+    path = str(tmp_path / "d3.pt")
+    torch.manual_seed(0)
+    model, hist = train_unet(tl, tl, _norm(), 1, "cuda", out_ch=8, lam_grad=0.1, lam_w=0.5, epochs=1, base=8, P=5,
+                             film_hidden=16, save_path=path, multiscale=0, amp=True, lam_grad_warmup_start=0,
+                             lam_grad_warmup_end=0, param_scaler=(np.zeros(5, np.float32), np.ones(5, np.float32)),
+                             param_keys=["a", "b", "c", "d", "e"], grad_accum_steps=2)
+    assert all(np.isfinite(v).all() for v in hist.values()) and hist["va_mse"][0] <= 5.0    # the reference's smoke bound
+    m2, norm2, (mu, std), pt, pk = load_checkpoint(path, "cuda")
+    assert pk == ["a", "b", "c", "d", "e"] and pt is None and mu.shape == (5,)
+    out = predict_fields(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy())
+    te = predict_te(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy())
+    assert out.shape == (8, 32, 16) and np.isfinite(out).all()
+    # two forwards differ in the last bits (fp32 atomic order in the GroupNorm statistics)
+    np.testing.assert_allclose(te, out[0], rtol=1e-4, atol=1e-5 * np.abs(out[0]).max())
+    with pytest.raises(ValueError):
+        predict_fields(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy(), Rn=np.zeros((3, 3)), Zn=np.zeros((3, 3)))
