@@ -60,7 +60,10 @@ def pack(L, dtype, mode, tflip, w, Cout, Cin, rows, k):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 8, 8, 16), (1, 13, 7, 16, 24), (2, 32, 16, 32, 64), (1, 8, 8, 64, 128),
-                                             (3, 5, 3, 8, 8)])
+                                             (3, 5, 3, 8, 8),
+                                             # shapes that take the weights-stationary bf16 kernel (W >= 16), one per tile config
+                                             (2, 32, 32, 64, 32), (2, 16, 16, 128, 128), (1, 16, 32, 256, 64), (3, 20, 24, 32, 32),
+                                             (1, 24, 16, 256, 256), (2, 40, 48, 8, 32), (1, 16, 16, 128, 64), (1, 32, 16, 64, 24)])
 def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(B * 1000 + H + Cin)
     x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
@@ -88,6 +91,24 @@ def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
                                     L.ptr(dx), Cin, H, W, 0, None, 0, L.stream_ptr()))
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(dx, Cin), dref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 64), (128, 32), (256, 128), (64, 256)])
+def test_conv1x1_weights_stationary_accumulate(L, Cin, Cout):
+    dtype, B, H, W = 1, 2, 24, 32
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5, dtype)
+    base = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    ref = F.conv2d(x, w) + base
+    xd = nhwc(x, dtype, ld=Cin + 16)
+    yd = nhwc(base, dtype, ld=Cout + 8)
+    wp = pack(L, dtype, L.SX_CONV1, 0, w, Cout, Cin, Cout, Cin)
+    L.check(L.lib().sx_conv_forward(dtype, L.SX_CONV1, B, H, W, Cin, Cout, L.ptr(xd), Cin + 16, H, W, L.ptr(wp), None,
+                                    L.ptr(yd), Cout + 8, H, W, 1, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yd, Cout), ref) < TOL[dtype]
+    assert float(yd[..., Cout:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

@@ -1,0 +1,44 @@
+// Shared declarations of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_ws.hip).
+#pragma once
+#include "sx_common.h"
+
+namespace sx {
+
+static constexpr int ROWB = 96;   // LDS bytes per staged row (64 payload + 32 pad)
+
+struct ConvArgs {
+  const void* x; const void* w; void* y; const float* bias; float* gn_stats;
+  int B, H, W;
+  int Hx, Wx, x_ld;
+  int Hy, Wy, y_ld;
+  int K, KPad;        // GEMM-K channels per tap (real / padded)
+  int R, RPad, RTot;  // output channels (real / padded per tap group / rows per tap in `w`)
+  int ntaps, tapw;
+  int in_scale, pad;
+  int shuffle, accumulate;
+  int tw_log2, TW, TH, LW, LH;
+  int tiles_x, tiles_y;
+  int cpg;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  __device__ static __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // 16 k-values per chunk: lane group g owns k = 4g..4g+3, MFMA step s consumes element s of
+  // every group (a consistent permutation of k on both operands).
+  __device__ static __forceinline__ f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+  }
+};
+
+
+// weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
+int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st);
+
+}  // namespace sx

@@ -15,42 +15,9 @@
 //   - the weight slice     [ntaps][BMC rows] x 64 B
 // into LDS (rows padded to 96 B: conflict-free for the ds_read_b128 fragment reads), then every
 // wave runs ntaps x MI x NI MFMAs on fragments read straight from those two images.
-#include "sx_common.h"
+#include "conv_common.h"
 
 namespace sx {
-
-static constexpr int ROWB = 96;   // LDS bytes per staged row (64 payload + 32 pad)
-
-struct ConvArgs {
-  const void* x; const void* w; void* y; const float* bias; float* gn_stats;
-  int B, H, W;
-  int Hx, Wx, x_ld;
-  int Hy, Wy, y_ld;
-  int K, KPad;        // GEMM-K channels per tap (real / padded)
-  int R, RPad, RTot;  // output channels (real / padded per tap group / rows per tap in `w`)
-  int ntaps, tapw;
-  int in_scale, pad;
-  int shuffle, accumulate;
-  int tw_log2, TW, TH, LW, LH;
-  int tiles_x, tiles_y;
-  int cpg;
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-  __device__ static __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  // 16 k-values per chunk: lane group g owns k = 4g..4g+3, MFMA step s consumes element s of
-  // every group (a consistent permutation of k on both operands).
-  __device__ static __forceinline__ f32x4 run(f32x4 a, f32x4 b, f32x4 c) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
-    return c;
-  }
-};
 
 template <typename T, int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -354,5 +321,9 @@ extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin
   a.tiles_x = cdiv(W, a.TW);
   a.tiles_y = cdiv(H, a.TH);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) {
+    const int rc = conv_ws_try(a, mode, st);   // 0 = launched, 1 = shape not covered, <0 = error
+    if (rc <= 0) return rc;
+  }
   return dtype == SX_BF16 ? conv_dispatch<bf16>(a, st) : conv_dispatch<float>(a, st);
 }
