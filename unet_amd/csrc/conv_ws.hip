@@ -17,10 +17,28 @@
 
 namespace sx {
 
-// 64 zero bytes: the source of every halo / padding piece (LDS-DMA cannot write immediates)
-__device__ __attribute__((aligned(64))) unsigned g_zero_page[16];
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane ends with the total
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x124, 0xf, 0xf, false);   // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x122, 0xf, 0xf, false);   // row_ror:2
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x121, 0xf, 0xf, false);   // row_ror:1
+  return v;
+}
+
+// position of a tile inside the batch, advanced incrementally (no divisions in the loops)
+struct TilePos {
+  int b, ty, tx;
+  __device__ __forceinline__ void set(int t, int tiles_x, int tiles_y) {
+    tx = t % tiles_x; t /= tiles_x;
+    ty = t % tiles_y; b = t / tiles_y;
+  }
+  __device__ __forceinline__ void next(int tiles_x, int tiles_y) {
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++b; } }
+  }
+};
 
 template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
@@ -41,11 +59,13 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   const int n = lane & 15, g = lane >> 4;
   const int cb = blockIdx.y * BMC;
   const int ntiles = a.B * a.tiles_y * a.tiles_x;
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  // stages of this block: s = 0 .. nst-1, stage s = (tile t0 + (s / KCH) * gridDim.x, chunk s % KCH)
-  const int my_tiles = (ntiles - t + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nst = my_tiles * KCH;
+  // contiguous tile range per block: neighbouring tiles share halo rows in L2 and belong to the same sample,
+  // so the GroupNorm partial sums are flushed once per (block, sample) instead of once per tile
+  const int tpb = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = blockIdx.x * tpb;
+  const int t_end = min(ntiles, t_begin + tpb);
+  if (t_begin >= t_end) return;
+  const int nst = (t_end - t_begin) * KCH;
 
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(a.x);
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
@@ -65,46 +85,97 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         A[kc][tap][j] = v;
       }
 
-  // per-thread staging slots: piece p = tid + q*256 -> halo pixel r = p>>2, 16-byte part p&3
-  int st_ly[NP], st_lx[NP];
+  // ---- staging: piece p = tid + q*256 -> halo pixel r = p>>2 (ly, lx), 16-byte part p&3.
+  // Per image one buffer resource (num_records = image bytes): rows above / below the image fall outside it and
+  // the hardware returns zeros; columns left / right of the image are forced out of range by hand.
+  // (K chunks beyond the real channel count read neighbouring finite data; their packed weights are zero.)
+  const int row_bytes = a.Wx * a.x_ld * 2;
+  const int img_bytes = a.Hx * row_bytes;
+  int st_rel[NP], st_lx[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    const int r = (tid + q * 256) >> 2;
-    st_ly[q] = (tid + q * 256) < PIECES ? r / LW : -100000;    // padding lanes never pass the bounds test
-    st_lx[q] = r - (r / LW) * LW;
+    const int p = tid + q * 256;
+    const int r = p >> 2;
+    const int ly = r / LW, lx = r - ly * LW;
+    st_lx[q] = p < PIECES ? lx - PAD : -100000;
+    st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + (p & 3) * 16;
   }
-  const int part = tid & 3;
   const int frag_off = (wn * NI * LW + n) * 64 + g * 16;
-  const bf16* zero = reinterpret_cast<const bf16*>(g_zero_page);
 
-  // LDS-DMA: every wave issues exactly NP global_load_lds per stage (dummy stages read the zero page), so the
-  // vmcnt bookkeeping is uniform: before computing stage s at most (DIST-1)*NP younger loads may be pending.
-  auto issue_stage = [&](int s) {
-    char* buf = smem + (s % NBUF) * BUF + wid * 1024;
-    const bool live = s < nst;
-    const int kc = s % KCH;
-    int tt = blockIdx.x + (s / KCH) * (int)gridDim.x;
-    const int tx_i = tt % a.tiles_x; tt /= a.tiles_x;
-    const int ty_i = tt % a.tiles_y; tt /= a.tiles_y;
-    const int iy0 = ty_i * TH - PAD, ix0 = tx_i * TW - PAD;
-    const int c = kc * 32 + part * 8;
-    const bf16* base = xg + (int64_t)tt * a.Hx * a.Wx * a.x_ld + c;
+  TilePos ip;                     // issue position
+  ip.set(t_begin, a.tiles_x, a.tiles_y);
+  int ikc = 0, is = 0;
+  auto issue_stage = [&]() {
+    char* buf = smem + (is % NBUF) * BUF + wid * 1024;
+    const bool live = is < nst;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(xg + (int64_t)ip.b * a.Hx * a.Wx * a.x_ld), 0, live ? img_bytes : 0, 0x00020000);
+    const int x0 = ip.tx * TW;
+    const int tile_off = ip.ty * TH * row_bytes + x0 * a.x_ld * 2 + ikc * 64;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const int iy = iy0 + st_ly[q], ix = ix0 + st_lx[q];
-      const bf16* src = zero;
-      if (live && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.K) src = base + ((int64_t)iy * a.Wx + ix) * a.x_ld;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(buf + q * 4096), 16, 0, 0);
+      const unsigned ix = (unsigned)(x0 + st_lx[q]);
+      const unsigned off = ix < (unsigned)a.Wx ? (unsigned)(st_rel[q] + tile_off) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + q * 4096), 16, off, 0, 0, 0);
     }
+    ++is;
+    if (++ikc == KCH) { ikc = 0; ip.next(a.tiles_x, a.tiles_y); }
   };
 
 #pragma unroll
-  for (int s = 0; s < DIST; ++s) issue_stage(s);
+  for (int k = 0; k < DIST; ++k) issue_stage();
   const bool do_stats = a.gn_stats != nullptr;
   int s = 0;
+  TilePos cp;                     // compute position
+  cp.set(t_begin, a.tiles_x, a.tiles_y);
 
-  while (true) {
+  // epilogue addressing: lane (n, g) of frag (j, i) stores channels c0(j)..+3 of pixel (row wn*NI+i, column n)
+  const int out_row = a.Wy * a.y_ld;
+  const int lane_out = (wn * NI * a.Wy + n) * a.y_ld + cb + wm * MI * 16 + 4 * g;
+  f32x4 s1[MI], s2[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
+
+  auto flush_stats = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int cl = (wm * MI + j) * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row_sum16(s1[j][r]), t2 = row_sum16(s2[j][r]);
+        if (n == 0) {
+          sm_stat[(wn * BMC + cl + r) * 2 + 0] = t1;
+          sm_stat[(wn * BMC + cl + r) * 2 + 1] = t2;
+        }
+      }
+      s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s2[j] = s1[j];
+    }
+    // raw barrier: __syncthreads() would drain the LDS-DMA prefetches (vmcnt(0)); only LDS writes matter here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < BMC) {
+      const int c = cb + tid;
+      const int cend = min(a.R, cb + BMC);
+      if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
+        const int grp = c / a.cpg;
+        float t1 = 0.f, t2 = 0.f;
+        for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
+#pragma unroll
+          for (int w = 0; w < WN; ++w) {
+            t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
+            t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
+          }
+        const int G = a.R / a.cpg;
+        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
+        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // sm_stat may be rewritten by the next flush
+  };
+
+  for (int t = t_begin; t < t_end; ++t) {
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int j = 0; j < MI; ++j)
@@ -116,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       wait_vmcnt<(DIST - 1) * NP>();                 // this wave's pieces of stage s have landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
-      issue_stage(s + DIST);
+      issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
       const char* buf = smem + (s % NBUF) * BUF + frag_off;
 #pragma unroll
       for (int rr = 0; rr < NI + TAPW - 1; ++rr) {
@@ -137,64 +208,27 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       }
     }
 
-    // ---- epilogue of tile t
-    int tt = t;
-    const int tx_i = tt % a.tiles_x; tt /= a.tiles_x;
-    const int ty_i = tt % a.tiles_y; tt /= a.tiles_y;
-    const int b = tt;
-    const int ox = tx_i * TW + n;
+    // ---- epilogue of tile t = (cp.b, cp.ty, cp.tx)
+    bf16* ytile = yg + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y_ld;   // wave-uniform
+    const bool xvalid = cp.tx * TW + n < a.W;
+    const int rows_left = a.H - cp.ty * TH - wn * NI;          // valid rows of this wave's NI rows
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int cl = (wm * MI + j) * 16 + 4 * g;
-      const int c0 = cb + cl;
-      const bool cvalid = c0 < a.R;
-      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+      const bool cvalid = cb + (wm * MI + j) * 16 + 4 * g < a.R;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int oy = ty_i * TH + wn * NI + i;
         f32x4 v = acc[j][i];
-        if (cvalid && oy < a.H && ox < a.W) {
-          bf16* dst = yg + ((int64_t)(b * a.Hy + oy) * a.Wy + ox) * a.y_ld + c0;
+        if (cvalid && xvalid && i < rows_left) {
+          bf16* dst = ytile + (unsigned)(lane_out + i * out_row + j * 16);
           if (a.accumulate) v += load4(dst);
           store4(dst, v);
-          if (do_stats) { s1 += v; s2 += v * v; }
-        }
-      }
-      if (do_stats) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t1 = sum16(s1[r]), t2 = sum16(s2[r]);
-          if (n == 0) {
-            sm_stat[(wn * BMC + cl + r) * 2 + 0] = t1;
-            sm_stat[(wn * BMC + cl + r) * 2 + 1] = t2;
-          }
+          if (do_stats) { s1[j] += v; s2[j] += v * v; }
         }
       }
     }
-    if (do_stats) {
-      // raw barrier: __syncthreads() would drain the LDS-DMA prefetches (vmcnt(0)); only LDS writes matter here
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tid < BMC) {
-        const int c = cb + tid;
-        const int cend = min(a.R, cb + BMC);
-        if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
-          const int grp = c / a.cpg;
-          float t1 = 0.f, t2 = 0.f;
-          for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
-#pragma unroll
-            for (int w = 0; w < WN; ++w) {
-              t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
-              t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
-            }
-          const int G = a.R / a.cpg;
-          atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
-          atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
-        }
-      }
-    }
-    t += gridDim.x;
-    if (t >= ntiles) break;
+    const int b_done = cp.b;
+    cp.next(a.tiles_x, a.tiles_y);
+    if (do_stats && (t + 1 == t_end || cp.b != b_done)) flush_stats(b_done);
   }
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
 }
@@ -220,9 +254,10 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   const int ntiles = a.B * a.tiles_x * a.tiles_y;
   const int gy = cdiv(a.RTot, BMC);
   // persistent grid: about one block per CU (registers allow one wave per SIMD); light variants get two
-  int per_cu = (KCH * TAPS * MI <= 36) ? 2 : 1;
+  int per_cu = 1;
   if (const char* e = getenv("SX_WS_PER_CU")) per_cu = atoi(e);     // tuning knob
-  const int gx = std::max(1, std::min(ntiles, (256 * per_cu) / gy));
+  int gx = std::max(1, std::min(ntiles, (256 * per_cu) / gy));
+  gx = cdiv(ntiles, cdiv(ntiles, gx));       // contiguous tile ranges: no empty trailing blocks
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, a);
   SX_LAUNCH_CHECK("conv_ws");
   return SX_OK;
