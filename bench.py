@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=24)
     return ap.parse_args()
 
 
@@ -96,12 +96,13 @@ def conv_launches(B):
 
 def measure_conv_roofline(B, sx_dtype, reps=5):
     """Replay every conv launch of a step through sx_conv_forward between HIP events (torch events on the
-    stream the kernels are launched on).  Returns (total_flops, total_seconds, n_launches)."""
+    stream the kernels are launched on).  Returns (total_flops, total_seconds, n_launches, total_bytes) where
+    total_bytes is the algorithmic HBM traffic (input image read once + output written once, packed weights)."""
     from unet_amd import _lib as L
     lib = L.lib()
     tdt = torch.bfloat16 if sx_dtype == L.SX_BF16 else torch.float32
     g = torch.Generator(device="cuda").manual_seed(0)
-    total_fl, total_s, n = 0.0, 0.0, 0
+    total_fl, total_s, n, total_by = 0.0, 0.0, 0, 0.0
     st = torch.cuda.current_stream()
     for (mode, h, w, cin, cout, fl) in conv_launches(B):
         hx, wx, hy, wy = h, w, h, w
@@ -127,8 +128,9 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
         e1.synchronize()
         total_s += e0.elapsed_time(e1) * 1e-3 / reps
         total_fl += fl
+        total_by += (x.numel() + y.numel() + wp.numel()) * x.element_size()
         n += 1
-    return total_fl, total_s, n
+    return total_fl, total_s, n, total_by
 
 
 def cpu_baseline(batch, steps):
@@ -218,13 +220,15 @@ def main():
     if rank == 0:
         sx_dtype = L.SX_BF16 if a.dtype == "bf16" else L.SX_F32
         if not a.no_roofline:
-            fl, secs, n = measure_conv_roofline(a.batch, sx_dtype)
+            fl, secs, n, nbytes = measure_conv_roofline(a.batch, sx_dtype)
             peak = 2500.0 if a.dtype == "bf16" else 157.3
             ach = fl / secs / 1e12
-            line["roofline"] = {"kernel": "conv_igemm_kernel (all fprop/dgrad launches of one step)", "bound": "mfma",
+            line["roofline"] = {"kernel": "conv_ws_kernel + conv_igemm_kernel (all fprop/dgrad launches of one step)",
+                                "bound": "mfma",
                                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                 "traffic": None, "launches_per_step": n, "flops_per_step": fl,
-                                "seconds_per_step": round(secs, 6)}
+                                "seconds_per_step": round(secs, 6),
+                                "hbm_algorithmic_GBps": round(nbytes / secs / 1e9, 1), "hbm_frac": round(nbytes / secs / 8e12, 4)}
             step_flops = 7.272e9 * a.batch
             line["step_model_tflops"] = round(step_flops * a.steps / dt / 1e12, 2)
         if not a.no_cpu_baseline:

@@ -194,6 +194,36 @@ def test_conv_wgrad(L, dtype, mode, B, H, W, Cin, Cout):
     assert rel_err(dw.cpu() - 1.0, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("tgk", ["", "0", "1", "2"])
+@pytest.mark.parametrize("mode,B,H,W,Cin,Cout", [
+    # persistent bf16 tier (wgrad_ws.hip): one shape per (a fragments, b fragments, tile width) family
+    (0, 3, 24, 32, 32, 32), (0, 2, 16, 16, 64, 64), (0, 5, 13, 20, 8, 32), (0, 2, 16, 48, 16, 16), (0, 1, 32, 16, 128, 64),
+    (0, 2, 40, 16, 64, 128), (0, 2, 16, 8, 64, 64), (0, 3, 12, 9, 128, 32), (0, 1, 16, 16, 256, 128), (0, 2, 8, 8, 256, 256),
+    (1, 3, 24, 32, 32, 32), (1, 2, 16, 16, 64, 8), (1, 2, 20, 18, 128, 64), (1, 2, 16, 8, 64, 32), (1, 2, 9, 17, 32, 128)])
+def test_conv_wgrad_persistent_bf16(L, monkeypatch, tgk, mode, B, H, W, Cin, Cout):
+    """bf16 weight gradient on channel slices of wider buffers (ld > C), every tap-group split of the block grid."""
+    if tgk:
+        monkeypatch.setenv("SX_WG_TGK", tgk)
+    else:
+        monkeypatch.delenv("SX_WG_TGK", raising=False)
+    dtype = 1
+    g = torch.Generator().manual_seed(H * 7 + Cin + mode)
+    k = 3 if mode == 0 else 1
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, padding=k // 2)
+    xd, dyd = nhwc(x, dtype, ld=Cin + 8), nhwc(dy, dtype, ld=2 * Cout)
+    xd[..., Cin:] = 3.0          # neighbouring channels of the wider buffers must not leak in
+    dyd[..., Cout:] = -2.0
+    nb = L.lib().sx_conv_wgrad_workspace_bytes(mode, B, H, W, Cout, Cin)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.full((Cout, Cin, k, k), 1.0, dtype=torch.float32, device="cuda")
+    L.check(L.lib().sx_conv_wgrad(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), 2 * Cout, L.ptr(xd), Cin + 8, H, W,
+                                  L.ptr(dw), 1, L.ptr(ws), nb, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu() - 1.0, ref) < 2e-3       # exact bf16 products, fp32 accumulation: only summation order differs
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 8, 16), (3, 7, 5, 24), (2, 32, 16, 64)])
 def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):

@@ -14,7 +14,8 @@
 // Grid: (a-tiles of 16*MI) x (b-tiles of 64) x nsplit.  Every split walks its share of the
 // 128-pixel tiles and writes an fp32 slab; a second kernel sums the slabs in a fixed order
 // (deterministic) straight into the parameter-gradient tensor in PyTorch layout.
-#include "sx_common.h"
+#include "wgrad_common.h"
+#include <algorithm>
 
 namespace sx {
 
@@ -179,38 +180,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[a*sa + b*sb + tap*st] (+)= sum_s slab[s][tap][a][b]
-// Block = 16 consecutive b (one 64-byte segment of a slab row) x 16 split lanes; the lanes' partial sums are
-// combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntaps,
-                                                           int Ca, int Cb, int CaPad, int CbPad, int64_t sa, int64_t sb, int64_t st,
-                                                           int accumulate) {
-  __shared__ float red[16][17];
-  const int bchunks = (Cb + 15) >> 4;
-  const int64_t nrows = (int64_t)ntaps * Ca;
-  const int64_t slab_sz = (int64_t)ntaps * CaPad * CbPad;
-  const int e = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  for (int64_t blk = blockIdx.x; blk < nrows * bchunks; blk += gridDim.x) {
-    const int bc = (int)(blk % bchunks);
-    const int64_t row = blk / bchunks;
-    const int aa = (int)(row % Ca), tap = (int)(row / Ca);
-    const int b = bc * 16 + e;
-    float s = 0.f;
-    if (b < Cb) {
-      const float* src = slab + ((int64_t)tap * CaPad + aa) * CbPad + b;
-      for (int k = lane; k < nsplit; k += 16) s += src[k * slab_sz];
+// out[(a*Cb + b)*ntaps + tap] (+)= sum_s slab[s][tap][a][b]   (PyTorch layouts: conv W[co][ci][tap], convT W[ci][co][tap])
+// One launch reduces the slabs of many layers (descriptor table in the kernel arguments).  Unit of work = one
+// 256-byte segment of a slab row (64 consecutive b) x all splits: 16 threads x float4 along b, 16 split lanes whose
+// partial sums are combined through LDS in a fixed order (deterministic).
+struct WgReduceArgs { WgReduceDesc d[WG_MAX_REDUCE]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A) {
+  __shared__ f32x4 red[16][17];
+  int di = 0;
+  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
+  const WgReduceDesc& D = A.d[di];
+  const int bchunks = (D.Cb + 63) >> 6;
+  const int64_t nunits = (int64_t)D.ntaps * D.Ca * bchunks;
+  const int64_t slab_sz = (int64_t)D.ntaps * D.CaPad * D.CbPad;
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
+    const int bc = (int)(u % bchunks);
+    const int64_t row = u / bchunks;
+    const int aa = (int)(row % D.Ca), tap = (int)(row / D.Ca);
+    const int b = bc * 64 + e * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (b < D.CbPad) {
+      const float* src = D.slab + ((int64_t)tap * D.CaPad + aa) * D.CbPad + b;
+      for (int k = sl; k < D.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
     }
-    red[lane][e] = s;
+    red[sl][e] = s;
     __syncthreads();
-    if (lane == 0 && b < Cb) {
-      float t = 0.f;
+    if (sl < 4) {                        // thread (e, sl) finishes column b + sl
+      const int bb = b + sl;
+      if (bb < D.Cb) {
+        float t = 0.f;
 #pragma unroll
-      for (int l = 0; l < 16; ++l) t += red[l][e];
-      float* dst = out + aa * sa + b * sb + tap * st;
-      *dst = accumulate ? (*dst + t) : t;
+        for (int l = 0; l < 16; ++l) t += red[l][e][sl];
+        float* dst = D.out + ((int64_t)aa * D.Cb + bb) * D.ntaps + tap;
+        *dst = D.accumulate ? (*dst + t) : t;
+      }
     }
     __syncthreads();
   }
+}
+
+int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += WG_MAX_REDUCE) {
+    WgReduceArgs A;
+    A.n = std::min(WG_MAX_REDUCE, n - i0);
+    int blk = 0;
+    for (int i = 0; i < A.n; ++i) {
+      A.d[i] = descs[i0 + i];
+      const int64_t units = (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
+      A.d[i].blk0 = blk;
+      A.d[i].nblk = (int)std::min<int64_t>(units, 1024);
+      blk += A.d[i].nblk;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blk), dim3(256), 0, st, A);
+    SX_LAUNCH_CHECK("wgrad_reduce");
+  }
+  return SX_OK;
 }
 
 struct WgPlan { int MI, nbf, items, a_tiles, b_tiles, nsplit, tiles_per_split; size_t ws_bytes; };
@@ -295,15 +321,16 @@ using namespace sx;
 extern "C" int64_t sx_conv_wgrad_workspace_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
   WgradArgs a;
   memset(&a, 0, sizeof(a));
-  // slab size does not depend on dtype; the tile count does, so size for the finer (fp32) tiling
+  // slab size does not depend on dtype; the tile count does, so size for the finer (fp32) tiling.  The bf16 tier
+  // (wgrad_ws.hip) may fall back to the generic kernel, so the workspace covers both.
   if (wgrad_geom(mode, SX_F32, B, H, W, a) != SX_OK) return -1;
-  return (int64_t)wgrad_plan(mode, B, H, W, Ca, Cb, a).ws_bytes;
+  return std::max<int64_t>((int64_t)wgrad_plan(mode, B, H, W, Ca, Cb, a).ws_bytes, wgrad_ws_slab_bytes(mode, B, H, W, Ca, Cb));
 }
 
-extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
-                             const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                             float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
-  SX_REQUIRE(P && Q && dw && workspace, "sx_conv_wgrad: null pointer");
+namespace sx {
+int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st) {
+  SX_REQUIRE(P && Q && slab && desc, "sx_conv_wgrad: null pointer");
   SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_wgrad: bad dtype %d", dtype);
   const int EPL = dtype == SX_BF16 ? 8 : 4;
   if (Ca % EPL || Cb % EPL || p_ld % EPL || q_ld % EPL) {
@@ -311,29 +338,43 @@ extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, i
     return SX_ERR_UNSUPPORTED;
   }
   SX_REQUIRE(((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0, "sx_conv_wgrad: misaligned pointer");
-  SX_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "sx_conv_wgrad: bad output channel counts");
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));
   if (mode == SX_CONVT_FWD) SX_REQUIRE(Hq >= 2 * H && Wq >= 2 * W, "sx_conv_wgrad: convT Q dims");
   else SX_REQUIRE(Hq == H && Wq == W, "sx_conv_wgrad: Q dims");
+  if (dtype == SX_BF16 && (int64_t)H * W * std::max(p_ld, q_ld) * 2 < ((int64_t)1 << 30)) {
+    const int64_t need = wgrad_ws_slab_bytes(mode, B, H, W, Ca, Cb);
+    if (need > 0) {
+      SX_REQUIRE(need <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %lld)", (long long)slab_bytes, (long long)need);
+      const int rc = wgrad_ws_try(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, (float*)slab, desc, st);
+      if (rc <= 0) return rc;
+    }
+  }
   WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a);
-  SX_REQUIRE((int64_t)p.ws_bytes <= workspace_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
-             (long long)workspace_bytes, p.ws_bytes);
-  a.P = P; a.Q = Q; a.slab = (float*)workspace;
+  SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
+             (long long)slab_bytes, p.ws_bytes);
+  a.P = P; a.Q = Q; a.slab = (float*)slab;
   a.B = B; a.H = H; a.W = W; a.Hq = Hq; a.Wq = Wq; a.p_ld = p_ld; a.q_ld = q_ld;
   a.Ca = Ca; a.Cb = Cb; a.CaPad = round_up(Ca, 16); a.CbPad = round_up(Cb, 16);
   a.nbf = p.nbf; a.tiles_per_split = p.tiles_per_split;
-  hipStream_t st = (hipStream_t)stream;
   int rc;
   if (dtype == SX_BF16) rc = p.MI == 4 ? wgrad_items<bf16, 4>(a, p, st) : wgrad_items<bf16, 2>(a, p, st);
   else rc = p.MI == 4 ? wgrad_items<float, 4>(a, p, st) : wgrad_items<float, 2>(a, p, st);
   SX_TRY(rc);
-  // PyTorch layouts: conv (a=co,b=ci): W[co][ci][tap] ; convT (a=ci,b=co): W[ci][co][tap]
-  const int64_t sa = (int64_t)Cb_out * a.ntaps, sb = a.ntaps, stp = 1;
-  const int blocks = (int)std::min<int64_t>((int64_t)a.ntaps * Ca_out * cdiv(Cb_out, 16), 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit,
-                     a.ntaps, Ca_out, Cb_out, a.CaPad, a.CbPad, sa, sb, stp, accumulate);
-  SX_LAUNCH_CHECK("wgrad_reduce");
+  desc->slab = (const float*)slab; desc->nsplit = p.nsplit; desc->ntaps = a.ntaps; desc->CaPad = a.CaPad; desc->CbPad = a.CbPad;
   return SX_OK;
+}
+}  // namespace sx
+
+extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
+                             const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                             float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  SX_REQUIRE(dw, "sx_conv_wgrad: null pointer");
+  SX_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "sx_conv_wgrad: bad output channel counts");
+  WgReduceDesc d;
+  memset(&d, 0, sizeof(d));
+  SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, workspace, workspace_bytes, &d, (hipStream_t)stream));
+  d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = accumulate;
+  return wgrad_reduce_multi(&d, 1, (hipStream_t)stream);
 }

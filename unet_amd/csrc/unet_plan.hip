@@ -10,6 +10,7 @@
 // and its GroupNorm statistics for backward.
 #include "sx_common.h"
 #include "film.h"
+#include "wgrad_common.h"
 #include <vector>
 
 namespace sx {
@@ -144,18 +145,22 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   p.sums_begin = off;
   for (auto& b : p.blk) { b.sums1 = take((int64_t)B * b.C * 4 * 4); b.sums2 = take((int64_t)B * b.C * 4 * 4); }
   p.sums_end = off;
-  // wgrad slabs: the largest any layer needs
+  // wgrad slabs: every layer of a backward half keeps its own slab until the fused reduction at the end of the half
+  // (WgQueue flushes early if it ever runs out, so this is a capacity, not a requirement)
   int64_t wgmax = 0;
+  auto wneed = [&](int mode, int h, int w, int ca, int cb) {
+    wgmax += (int64_t)align_up((size_t)sx_conv_wgrad_workspace_bytes(mode, B, h, w, ca, cb), 256);
+  };
   for (auto& b : p.blk) {
-    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV3, B, b.H, b.W, b.C, b.C));
-    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV3, B, b.H, b.W, b.C, b.Cin));
-    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV1, B, b.H, b.W, b.C, b.Cin));
+    wneed(SX_CONV3, b.H, b.W, b.C, b.C);
+    wneed(SX_CONV3, b.H, b.W, b.C, b.Cin);
+    wneed(SX_CONV1, b.H, b.W, b.C, b.Cin);
   }
   for (int j = 0; j < D; ++j) {
     const int l = D - 1 - j;
-    wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l]));
+    wneed(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l]);
   }
-  wgmax = std::max(wgmax, sx_conv_wgrad_workspace_bytes(SX_CONV1, B, d.H, d.W, p.out_pad, p.C[0]));
+  wneed(SX_CONV1, d.H, d.W, p.out_pad, p.C[0]);
   p.wg_ws_bytes = wgmax;
   p.wg_ws = take(wgmax);
   p.ws_bytes = off;
@@ -225,6 +230,34 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   return film_backward(fa, wg, st);
 }
 
+// ---------------------------------------------------------------- weight-gradient queue
+// Every layer's split-K kernel writes its own slab; ONE fused launch reduces them all at the end of a backward half
+// (25 tiny reduce launches per step were ~8 % of the step).
+struct WgQueue {
+  char* base; int64_t cap, used; int dtype, B, acc; hipStream_t st;
+  std::vector<WgReduceDesc> pending;
+  WgQueue(const Plan& p, void* ws, int acc_, hipStream_t st_)
+      : base((char*)ws + p.wg_ws), cap(p.wg_ws_bytes), used(0), dtype(p.d.dtype), B(p.d.B), acc(acc_), st(st_) {}
+  int flush() {
+    if (!pending.empty()) SX_TRY(wgrad_reduce_multi(pending.data(), (int)pending.size(), st));
+    pending.clear();
+    used = 0;
+    return SX_OK;
+  }
+  int add(int mode, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out, const void* P, int p_ld, const void* Q, int q_ld,
+          int Hq, int Wq, float* dw) {
+    const int64_t need = (int64_t)align_up((size_t)sx_conv_wgrad_workspace_bytes(mode, B, H, W, Ca, Cb), 256);
+    if (used + need > cap) SX_TRY(flush());
+    WgReduceDesc d;
+    memset(&d, 0, sizeof(d));
+    SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, base + used, cap - used, &d, st));
+    d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = acc;
+    pending.push_back(d);
+    used += need;
+    return SX_OK;
+  }
+};
+
 // ---------------------------------------------------------------- one DoubleConv block
 static int block_forward(const Plan& p, int k, const float* const* params, const void* wpack, void* ws, bool film,
                          const float* drop, hipStream_t st) {
@@ -248,7 +281,7 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
 
 // d_out is read from b.dO.  Writes parameter gradients (if wg) and the input gradient into b.dX (if need_dx).
 static int block_backward(const Plan& p, int k, const float* const* params, float* const* grads, const void* wpack, void* ws,
-                          bool film, const float* drop, bool need_dx, int flags, hipStream_t st) {
+                          bool film, const float* drop, bool need_dx, int flags, WgQueue& wq, hipStream_t st) {
   const BlockBuf& b = p.blk[k];
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
@@ -265,8 +298,7 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
                              wg ? grads[b.pidx + 4] : nullptr, wg ? grads[b.pidx + 5] : nullptr, acc, st));
   const void* dR = keep_r ? at(ws, b.dR) : at(ws, b.dO);
   if (wg)
-    SX_TRY(sx_conv_wgrad(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W,
-                         grads[b.pidx + 3], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
+    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w2d), nullptr,
                          at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
   // through SiLU / GN1 (dY buffer is reused for dY1)
@@ -274,10 +306,8 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
                              at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY), b.C,
                              nullptr, 0, wg ? grads[b.pidx + 1] : nullptr, wg ? grads[b.pidx + 2] : nullptr, acc, st));
   if (wg) {
-    SX_TRY(sx_conv_wgrad(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY), b.C, at(ws, b.in), b.in_ld, b.H, b.W,
-                         grads[b.pidx + 0], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
-    SX_TRY(sx_conv_wgrad(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, b.C, at(ws, b.in), b.in_ld, b.H, b.W,
-                         grads[b.pidx + 6], acc, at(ws, p.wg_ws), p.wg_ws_bytes, st));
+    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY), b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
+    SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
   }
   if (need_dx) {
     SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
@@ -445,11 +475,12 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
       if (e != hipSuccess) return hip_fail(e, "memset(dparams)");
     }
   }
+  WgQueue wq(p, ws, acc, st);
   // head
   const BlockBuf& last = p.blk[2 * D];
   if (wg) {
-    SX_TRY(sx_conv_wgrad(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
-                         at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
+    SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
+                  at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
     float* db = grads[p.out_pidx + 1];
     if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)d->out_ch * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
     SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, db, stream));
@@ -458,20 +489,21 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
                          nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
   for (int j = D - 1; j >= 0; --j) {
     const int l = D - 1 - j, k = D + 1 + j;
-    SX_TRY(block_backward(p, k, params, grads, wpack, ws, film, drop ? drop[j] : nullptr, true, flags, st));
+    SX_TRY(block_backward(p, k, params, grads, wpack, ws, film, drop ? drop[j] : nullptr, true, flags, wq, st));
     const BlockBuf& prev = p.blk[k - 1];
     const int Hs = 2 * p.H[l + 1], Ws = 2 * p.W[l + 1];
     if (wg) {
       float* db = grads[p.up_pidx[j] + 1];
       if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)p.C[l] * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
       SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
-      SX_TRY(sx_conv_wgrad(dt, SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
-                           at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]], acc, at(ws, p.wg_ws), p.wg_ws_bytes, stream));
+      SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
+                    at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]]));
     }
     // gradient w.r.t. the transposed conv's input = d_out of the previous block
     SX_TRY(sx_conv_forward(dt, SX_CONVT_BWD, B, p.H[l + 1], p.W[l + 1], p.C[l], p.C[l + 1], at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l],
                            at(wpack, p.upb[j]), nullptr, at(ws, prev.dO), p.C[l + 1], p.H[l + 1], p.W[l + 1], 0, nullptr, 0, stream));
   }
+  SX_TRY(wq.flush());
   if (film) SX_TRY(film_run_backward(p, D + 1, 2 * D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }
@@ -495,15 +527,17 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
       if (e != hipSuccess) return hip_fail(e, "memset(dparams)");
     }
   }
+  WgQueue wq(p, ws, (flags & SX_BWD_ACCUMULATE) ? 1 : 0, st);
   // bottleneck: d_out already in blk[D].dO ; skips' gradients in dcat[l] upper halves
-  SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, st));
+  SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, wq, st));
   for (int l = D - 1; l >= 0; --l) {
     const BlockBuf& b = p.blk[l];
     const BlockBuf& nxt = p.blk[l + 1];   // its dX is d(pool_l)
     SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
                                     at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
-    SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, st));
+    SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, wq, st));
   }
+  SX_TRY(wq.flush());
   if (film) SX_TRY(film_run_backward(p, 0, D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }

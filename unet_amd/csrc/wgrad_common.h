@@ -1,0 +1,31 @@
+// Shared declarations of the weight-gradient kernels (conv_wgrad.hip: generic tier + slab reduction,
+// wgrad_ws.hip: persistent LDS-DMA bf16 tier).
+#pragma once
+#include "sx_common.h"
+
+namespace sx {
+
+// One pending slab reduction: out[(a*Cb + b)*ntaps + tap] (+)= sum_s slab[s][tap][a][b]
+struct WgReduceDesc {
+  const float* slab;
+  float* out;
+  int nsplit, ntaps, Ca, Cb, CaPad, CbPad;   // Ca / Cb: channels actually written (<= padded slab extents)
+  int accumulate;
+  int blk0, nblk;                            // block range inside a fused launch (filled by wgrad_reduce_multi)
+};
+static constexpr int WG_MAX_REDUCE = 40;     // descriptors per fused launch (kernel-argument budget)
+
+// Fused reduction of up to WG_MAX_REDUCE pending slabs (more are split over several launches).
+int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st);
+
+// Launches the split-K kernel of one layer into `slab` and fills `desc` (slab, nsplit, ntaps, CaPad, CbPad).
+// The caller completes desc (out, Ca, Cb, accumulate) and reduces now or later.
+int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st);
+
+// Persistent bf16 tier.  slab bytes it needs (0 = shape not covered) / launch (0 = launched, 1 = not covered, <0 error).
+int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb);
+int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld,
+                 float* slab, WgReduceDesc* desc, hipStream_t st);
+
+}  // namespace sx

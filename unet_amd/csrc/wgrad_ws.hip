@@ -1,0 +1,433 @@
+// Persistent split-K weight-gradient kernel, bf16, gfx950: the fast tier of sx_conv_wgrad for 3x3 / 1x1 convolutions.
+//
+//     dW[tap][a][b] = sum over pixels p of  P[p][a] * Q[p + tap - pad][b]        (P = dY, Q = layer input)
+//
+// The reduction dimension is the pixel index (up to 524k per layer at batch 64) and the result is tiny
+// (taps x Ca x Cb), so a block keeps ALL its accumulators in registers while it walks a contiguous range of
+// 128-pixel tiles, and writes one fp32 slab at the very end:
+//   * both operand tiles are filled by LDS-DMA (raw buffer loads, 16 bytes per lane straight into LDS, hardware
+//     zero fill outside the image) into a ring of NBUF stages: no staging registers, no address arithmetic beyond
+//     one 32-bit add per piece, loads of the next tiles stay in flight under the MFMAs of the current one;
+//   * pixel-major tiles are consumed through ds_read_b64_tr_b16 (hardware transpose: 8 consecutive pixels of one
+//     channel per lane = the MFMA k layout).  The 16-byte pieces of a pixel are XOR-swizzled by the pixel's
+//     position so the 8 rows a 32-lane half reads land on 8 distinct 32-byte bank segments (the DMA applies the
+//     permutation for free: it only decides which global piece a lane fetches);
+//   * the (a tile, b tile, tap group) space is divided among R blocks that share a pixel range and are placed on
+//     the same XCD (same L2), and the pixel range is split S ways with S*R ~ number of CUs: fewer, larger slabs
+//     than a plain split-K over every CU (slab traffic, not operand traffic, dominated the first version).
+#include "wgrad_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace sx {
+
+struct WgWsArgs {
+  const bf16* P; const bf16* Q; float* slab;
+  int B, H, W, p_ld, q_ld;
+  int Ca, Cb, CaPad, CbPad;
+  int a_tiles, b_tiles, tg_count, R, S;
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int dbg;
+  unsigned long long* stamps;   // diagnostic build only
+};
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Byte offset of 16-byte piece c of pixel (y, x) inside a tile image with `pitch` pixel slots per row and RB bytes
+// per pixel.  An involution on (x, c) for fixed y, so the same function maps "slot -> what to fetch" for the DMA.
+template <int RB, int TWL>
+__device__ __forceinline__ int wg_tile_off(int y, int x, int pitch, int c) {
+  const int sb = TWL == 4 ? ((x >> 3) & 1) : (y & 1);
+  if constexpr (RB == 128) {
+    const int s2 = ((x >> 1) & 1) | (sb << 1);
+    return ((y * pitch + x) * 8 + (c ^ (2 * s2))) * 16;
+  } else if constexpr (RB == 64) {
+    return ((y * pitch + x) * 4 + (c ^ (2 * sb))) * 16;
+  } else {
+    return ((y * pitch + (x ^ (sb << 2))) * 2 + c) * 16;
+  }
+}
+
+// One MFMA operand = two ds_read_b64_tr_b16 results (k = 8g .. 8g+3 and 8g+4 .. 8g+7 of one channel per lane).
+struct WgFrag {
+  s16x4 lo, hi;
+  __device__ __forceinline__ bf16x8 v() const {
+    union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+    u.s.l = lo; u.s.h = hi;
+    return u.v;
+  }
+};
+template <int OFF>
+__device__ __forceinline__ void wg_issue_tr(WgFrag& f, unsigned a0, unsigned a1) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a0), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a1), "n"(OFF));
+}
+// placed after the s_waitcnt that covers the reads: ties the consumers of f behind that wait
+__device__ __forceinline__ void wg_landed(WgFrag& f) {
+  asm volatile("" : "+v"(f.lo));
+  asm volatile("" : "+v"(f.hi));
+}
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    wg_static_for<N, F, I + 1>(static_cast<F&&>(f));
+  }
+}
+
+struct WgTilePos {
+  int b, ty, tx;
+  __device__ __forceinline__ void set(int t, int tiles_x, int tiles_y) {
+    tx = t % tiles_x; t /= tiles_x;
+    ty = t % tiles_y; b = t / tiles_y;
+  }
+  __device__ __forceinline__ void next(int tiles_x, int tiles_y) {
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++b; } }
+  }
+};
+
+// TAPS: 9 (3x3, pad 1) or 1.  TGH x TGW: the rectangle of taps one block owns.  MI / NBF: 16-channel fragments of
+// the block's a (P) / b (Q) range.  TWL: log2 of the tile width (16x8 or 8x16 pixels).
+static constexpr bool DBG = false;  // SX_WG_DBG ablation switches (bit 0: no MFMA loop, bit 1: no operand traffic)
+
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF>
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
+  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr int TW = 1 << TWL, TH = 128 / TW, YS = 32 / TW;
+  constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
+  constexpr int PB = MI * 32, QB = NBF * 32;
+  constexpr int PP = PB / 16, QP = QB / 16;
+  constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
+  constexpr int NPP = (128 * PP) / 256;
+  constexpr int QSLOTS = LH * QPITCH * QP;
+  constexpr int NPQ = (QSLOTS + 255) / 256;
+  constexpr int NPT = NPP + NPQ;
+  constexpr int BUF = NPT * 4096;
+  constexpr int DIST = NBUF - 1;
+  constexpr int NIT = TGH * TGW * NBF, ITEMS = (NIT + 3) / 4;
+  static_assert(NPP >= 1, "P tile smaller than one DMA round");
+  extern __shared__ __align__(16) char smem[];
+  const unsigned long long t_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
+
+  // waves 0-3 compute (one per SIMD), waves 4-7 only feed the LDS ring: a wave that issues an LDS-DMA instruction is
+  // held for ~50 cycles per KB, which would otherwise come straight out of the MFMA stream of a one-wave SIMD
+  const int wid8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = wid8 >= 4;
+  const int wid = wid8 & 3, tid = threadIdx.x & 255, lane = tid & 63;
+  const int n = lane & 15, g = lane >> 4, q4 = n >> 2, p4 = n & 3;
+
+  // ---- which part of the problem: partners (same pixel range, different r) are 8 block ids apart = same XCD
+  const int id = blockIdx.x, xcd = id & 7, wq = id >> 3;
+  const int split = (wq / a.R) * 8 + xcd;
+  int r = wq % a.R;
+  if (split >= a.S) return;
+  const int tg = r % a.tg_count; r /= a.tg_count;
+  const int tb = r % a.b_tiles, ta = r / a.b_tiles;
+  const int a0 = ta * (MI * 16), b0 = tb * (NBF * 16);
+  const int oy = TGH == 3 ? 0 : (TGW == 3 ? tg : tg / 3);
+  const int ox = TGW == 3 ? 0 : (TAPS == 9 ? tg % 3 : 0);
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int nst = t_end - t_begin;
+
+  // ---- DMA setup: slot e = tid + q*256 of the P / Q image -> (pixel, piece) it holds -> global offset
+  const int prow_bytes = a.W * a.p_ld * 2, qrow_bytes = a.W * a.q_ld * 2;
+  const int pimg_bytes = a.H * prow_bytes, qimg_bytes = a.H * qrow_bytes;
+  int p_rel[NPP], p_x[NPP], q_rel[NPQ], q_x[NPQ];
+#pragma unroll
+  for (int q = 0; q < NPP; ++q) {
+    const int e = tid + q * 256;
+    const int ps = e / PP, cs = e % PP;
+    const int y = ps >> TWL, xs = ps & (TW - 1);
+    // invert the swizzle: the involution maps the slot's (xs, cs) to the (x, c) stored there
+    const int o = wg_tile_off<PB, TWL>(y, xs, TW, cs) >> 4;
+    const int x = (o / PP) & (TW - 1), c = o % PP;
+    const bool ok = a0 + c * 8 < a.Ca;
+    p_x[q] = ok ? x : -100000;
+    p_rel[q] = y * prow_bytes + x * a.p_ld * 2 + (a0 + c * 8) * 2;
+  }
+#pragma unroll
+  for (int q = 0; q < NPQ; ++q) {
+    const int e = tid + q * 256;
+    const int ps = e / QP, cs = e % QP;
+    const int y = ps / QPITCH, xs = ps - y * QPITCH;
+    const int o = wg_tile_off<QB, TWL>(y, xs, QPITCH, cs) >> 4;
+    const int x = (o / QP) - y * QPITCH, c = o % QP;
+    const bool ok = y < LH && x < LW && b0 + c * 8 < a.Cb;
+    q_x[q] = ok ? x + ox - PAD : -100000;
+    q_rel[q] = (y + oy - PAD) * qrow_bytes + (x + ox - PAD) * a.q_ld * 2 + (b0 + c * 8) * 2;
+  }
+
+  // A stage's NPT pieces are issued one by one (stage_begin, issue_piece<q> ..., stage_end) so the main loop can
+  // spread them between its k-steps: an LDS-DMA instruction holds the issuing wave for ~50 cycles of the CU's one
+  // texture-address unit, which other waves' MFMAs cover only if the four waves do not all issue at once.
+  WgTilePos ip;
+  ip.set(t_begin, a.tiles_x, a.tiles_y);
+  int is = 0;
+  __amdgpu_buffer_rsrc_t rp, rq;
+  int ix0 = 0, ipoff = 0, iqoff = 0;
+  char* ibuf = smem;
+  auto stage_begin = [&]() {
+    ibuf = smem + (is % NBUF) * BUF + wid * 1024;
+    const bool live = is < nst && !(DBG && (a.dbg & 2));
+    rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (int64_t)ip.b * a.H * a.W * a.p_ld), 0, live ? pimg_bytes : 0, 0x00020000);
+    rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Q + (int64_t)ip.b * a.H * a.W * a.q_ld), 0, live ? qimg_bytes : 0, 0x00020000);
+    ix0 = ip.tx * TW;
+    const int y0 = ip.ty * TH;
+    ipoff = y0 * prow_bytes + ix0 * a.p_ld * 2;
+    iqoff = y0 * qrow_bytes + ix0 * a.q_ld * 2;
+  };
+  auto issue_piece = [&](auto QI) {
+    constexpr int q = decltype(QI)::value;
+    if constexpr (q < NPP) {
+      const unsigned off = (unsigned)(ix0 + p_x[q]) < (unsigned)a.W ? (unsigned)(p_rel[q] + ipoff) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void*)(ibuf + q * 4096), 16, off, 0, 0, 0);
+    } else {
+      const unsigned off = (unsigned)(ix0 + q_x[q - NPP]) < (unsigned)a.W ? (unsigned)(q_rel[q - NPP] + iqoff) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(ibuf + q * 4096), 16, off, 0, 0, 0);
+    }
+  };
+  auto stage_end = [&]() {
+    ++is;
+    ip.next(a.tiles_x, a.tiles_y);
+  };
+  auto issue_stage = [&]() {
+    stage_begin();
+    wg_static_for<NPT>(issue_piece);
+    stage_end();
+  };
+
+  // ---- fragment addressing (stage-relative byte offsets, invariant over tiles)
+  const int yl = TWL == 4 ? (g >> 1) : g;
+  const int xl = (TWL == 4 ? 8 * (g & 1) : 0) + q4;
+  const int hh = p4 >> 1, lo = (p4 & 1) * 8;
+  int offP[MI][2];
+#pragma unroll
+  for (int j = 0; j < MI; ++j)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) offP[j][rd] = wg_tile_off<PB, TWL>(yl, xl + 4 * rd, TW, 2 * j + hh) + lo;
+  int offQ[ITEMS][2], it_tap[ITEMS], it_bf[ITEMS];
+  bool it_valid[ITEMS];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const int it = wid * ITEMS + t;
+    it_valid[t] = it < NIT;
+    const int itc = it_valid[t] ? it : 0;
+    const int tl = itc / NBF, bf = itc - tl * NBF;
+    const int dy = tl / TGW, dx = tl - dy * TGW;
+    it_tap[t] = TAPS == 9 ? (oy + dy) * 3 + (ox + dx) : 0;
+    it_bf[t] = bf;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd)
+      offQ[t][rd] = NPP * 4096 + wg_tile_off<QB, TWL>(yl + dy, xl + dx + 4 * rd, QPITCH, 2 * bf + hh) + lo;
+  }
+
+  f32x4 acc[ITEMS][MI];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (loader) {
+#pragma unroll
+    for (int k = 0; k < DIST; ++k) issue_stage();
+    for (int s = 0; s < nst; ++s) {
+      wg_wait_vmcnt<(DIST - 1) * NPT>();                 // this wave's pieces of stage s have landed
+      __builtin_amdgcn_s_barrier();                      // ... everyone's have, and buffer (s-1) % NBUF is free
+      issue_stage();                                     // stage s + DIST (dummy past the end: keeps vmcnt uniform)
+    }
+    wg_wait_vmcnt<0>();   // drain the dummy prefetches before the wave (and the block's LDS allocation) retires
+    return;
+  }
+
+  const unsigned sm0 = (unsigned)(uintptr_t)smem;
+  const unsigned long long t_setup = DBG ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long t_first = 0;
+  for (int s = 0; s < nst; ++s) {
+    __builtin_amdgcn_s_barrier();                        // stage s is in LDS (the loaders waited for it)
+    if (DBG && s == 0) t_first = __builtin_amdgcn_s_memtime();
+    const unsigned buf = sm0 + (s % NBUF) * BUF;
+    if (DBG && (a.dbg & 1)) continue;
+    unsigned aP[MI][2], aQ[ITEMS][2];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) { aP[j][0] = buf + offP[j][0]; aP[j][1] = buf + offP[j][1]; }
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) { aQ[t][0] = buf + offQ[t][0]; aQ[t][1] = buf + offQ[t][1]; }
+    // Transposed reads are issued from inline asm (the compiler would put s_waitcnt vmcnt(0) in front of any LDS
+    // read it can see while LDS-DMA is in flight) one k-step ahead of the MFMAs that consume them; every k-step
+    // starts with one lgkmcnt(0) for reads issued a whole k-step of MFMAs earlier.
+    WgFrag Af[2][MI], Bq[2][ITEMS];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) wg_issue_tr<0>(Af[0][j], aP[j][0], aP[j][1]);
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) wg_issue_tr<0>(Bq[0][t], aQ[t][0], aQ[t][1]);
+    wg_static_for<4>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value, cur = ks & 1, nxt = cur ^ 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < MI; ++j) wg_landed(Af[cur][j]);
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) wg_landed(Bq[cur][t]);
+      if constexpr (ks < 3) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) wg_issue_tr<(ks + 1) * 32 * PB>(Af[nxt][j], aP[j][0], aP[j][1]);
+      }
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) {
+        if constexpr (ks < 3) wg_issue_tr<(ks + 1) * YS * QPITCH * QB>(Bq[nxt][t], aQ[t][0], aQ[t][1]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[cur][t].v(), Af[cur][j].v(), acc[t][j], 0, 0, 0);
+      }
+    });
+  }
+
+  const unsigned long long t_loop = DBG ? __builtin_amdgcn_s_memtime() : 0;
+  // ---- slab[split][tap][a][b]: lane (n, g) of tile (t, j) holds b = b0 + 16*bf + 4g .. +3 of row a = a0 + 16*j + n
+  const int ntaps = TAPS;
+  float* slab = a.slab + (int64_t)split * ntaps * a.CaPad * a.CbPad;
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    if (!it_valid[t]) continue;
+    const int bcol = b0 + it_bf[t] * 16 + 4 * g;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int arow = a0 + j * 16 + n;
+      if (arow < a.CaPad && bcol < a.CbPad)
+        *reinterpret_cast<f32x4*>(slab + ((int64_t)it_tap[t] * a.CaPad + arow) * a.CbPad + bcol) = acc[t][j];
+    }
+  }
+  if (DBG && a.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    o[0] = t_entry; o[1] = t_setup; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
+    o[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// ------------------------------------------------------------------ host side
+struct WgWsPlan {
+  bool ok;
+  int taps, tgk;          // tgk: 0 = all taps per block, 1 = one tap row, 2 = one tap
+  int MI, NBF, TWL;
+  int a_tiles, b_tiles, tg_count, R, S;
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int CaPad, CbPad;
+  int64_t slab_bytes;
+};
+
+static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
+  WgWsPlan p;
+  memset(&p, 0, sizeof(p));
+  if (mode != SX_CONV3 && mode != SX_CONV1) return p;
+  if (W < 8 || Ca % 8 || Cb % 8) return p;
+  if ((int64_t)H * W * std::max(Ca, Cb) * 2 >= ((int64_t)1 << 30)) return p;   // 32-bit offsets inside one image
+  p.taps = mode == SX_CONV3 ? 9 : 1;
+  p.CaPad = round_up(Ca, 16); p.CbPad = round_up(Cb, 16);
+  p.MI = p.CaPad >= 64 ? 4 : p.CaPad / 16;      // 1, 2, (3 -> 4), 4
+  if (p.MI == 3) p.MI = 4;
+  p.NBF = p.CbPad >= 64 ? 4 : p.CbPad / 16;
+  if (p.NBF == 3) p.NBF = 4;
+  p.a_tiles = cdiv(p.CaPad, p.MI * 16);
+  p.b_tiles = cdiv(p.CbPad, p.NBF * 16);
+  p.TWL = W >= 16 ? 4 : 3;
+  const int TW = 1 << p.TWL, TH = 128 / TW;
+  p.tiles_x = cdiv(W, TW); p.tiles_y = cdiv(H, TH);
+  p.ntiles = B * p.tiles_x * p.tiles_y;
+  const double npix = (double)B * H * W;
+  const double out_bytes = (double)p.taps * p.CaPad * p.CbPad * 4;
+  const double flops = 2.0 * npix * p.taps * p.CaPad * p.CbPad;
+  const int force = getenv("SX_WG_TGK") ? atoi(getenv("SX_WG_TGK")) : -1;   // tuning knob
+  double best = 1e30;
+  for (int tgk = 0; tgk < (p.taps == 9 ? 3 : 1); ++tgk) {
+    if (force >= 0 && p.taps == 9 && tgk != force) continue;
+    if (force < 0 && tgk != 0) continue;      // measured: splitting the taps over blocks never paid on cfg A
+    const int tgc = tgk == 0 ? 1 : (tgk == 1 ? 3 : 9);
+    const int tgh = tgk == 0 ? (p.taps == 9 ? 3 : 1) : 1, tgw = (tgk == 2 || p.taps == 1) ? 1 : 3;
+    const int R = p.a_tiles * p.b_tiles * tgc;
+    int S = std::max(1, std::min(p.ntiles, 256 / R));
+    const int tps = cdiv(p.ntiles, S);
+    S = cdiv(p.ntiles, tps);
+    const double halo = (double)(TH + tgh - 1) * (TW + tgw - 1) / (TH * TW);
+    const double l2 = (double)R * npix * (p.MI * 32 + p.NBF * 32 * halo);
+    const double hbm = npix * (Ca + Cb) * 2;
+    const double fill = std::max(1.0, 256.0 / (S * R));
+    const double t = fill * std::max(std::max(l2 / 15e12, hbm / 5e12), flops / 1.2e15) + 2 * S * out_bytes / 4e12;
+    if (t < best) { best = t; p.tgk = tgk; p.tg_count = tgc; p.R = R; p.S = S; p.tiles_per_split = tps; }
+  }
+  p.slab_bytes = (int64_t)p.S * (int64_t)out_bytes;
+  p.ok = true;
+  return p;
+}
+
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL>
+static int launch_wgws(const WgWsArgs& a, hipStream_t st) {
+  constexpr int TW = 1 << TWL, TH = 128 / TW;
+  constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
+  constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
+  constexpr int NPT = (128 * MI * 2) / 256 + (LH * QPITCH * NBF * 2 + 255) / 256;
+  constexpr int NBUF = NPT * 4096 * 4 <= 160 * 1024 ? 4 : 3;
+  const size_t smem = (size_t)NBUF * NPT * 4096;
+  auto kern = wgrad_ws_kernel<TAPS, TGH, TGW, MI, NBF, TWL, NBUF>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad_ws)");
+    configured = true;
+  }
+  const int blocks = cdiv(a.S, 8) * 8 * a.R;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, a);
+  SX_LAUNCH_CHECK("wgrad_ws");
+  return SX_OK;
+}
+
+template <int TAPS, int TGH, int TGW, int TWL>
+static int wgws_pick_frag(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) {
+#define SX_WG_CASE(mi, nbf) \
+  if (p.MI == mi && p.NBF == nbf) return launch_wgws<TAPS, TGH, TGW, mi, nbf, TWL>(a, st);
+  if constexpr (TWL == 4) {
+    SX_WG_CASE(1, 1) SX_WG_CASE(1, 2) SX_WG_CASE(1, 4)
+    SX_WG_CASE(2, 1) SX_WG_CASE(2, 2) SX_WG_CASE(2, 4)
+    SX_WG_CASE(4, 1) SX_WG_CASE(4, 2) SX_WG_CASE(4, 4)
+  } else {
+    SX_WG_CASE(4, 4) SX_WG_CASE(4, 2) SX_WG_CASE(2, 4) SX_WG_CASE(2, 2)
+  }
+#undef SX_WG_CASE
+  return 1;
+}
+
+template <int TWL>
+static int wgws_pick_taps(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) {
+  if (p.taps == 1) return wgws_pick_frag<1, 1, 1, TWL>(p, a, st);
+  if (p.tgk == 0) return wgws_pick_frag<9, 3, 3, TWL>(p, a, st);
+  if (p.tgk == 1) return wgws_pick_frag<9, 1, 3, TWL>(p, a, st);
+  return wgws_pick_frag<9, 1, 1, TWL>(p, a, st);
+}
+
+int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
+  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
+  return p.ok ? p.slab_bytes : 0;
+}
+
+int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld,
+                 float* slab, WgReduceDesc* desc, hipStream_t st) {
+  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
+  if (!p.ok) return 1;
+  WgWsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = (const bf16*)P; a.Q = (const bf16*)Q; a.slab = slab;
+  a.B = B; a.H = H; a.W = W; a.p_ld = p_ld; a.q_ld = q_ld;
+  a.Ca = Ca; a.Cb = Cb; a.CaPad = p.CaPad; a.CbPad = p.CbPad;
+  a.a_tiles = p.a_tiles; a.b_tiles = p.b_tiles; a.tg_count = p.tg_count; a.R = p.R; a.S = p.S;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
+  a.dbg = getenv("SX_WG_DBG") ? atoi(getenv("SX_WG_DBG")) : 0;
+  a.stamps = getenv("SX_WG_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WG_STAMPS"), nullptr, 0) : nullptr;
+  const int rc = p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st);
+  if (rc != SX_OK) return rc;
+  desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad;
+  return SX_OK;
+}
+
+}  // namespace sx
