@@ -41,4 +41,16 @@ template <> struct Mma<float> {
 // weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st);
 
+// Weight packing for a whole table of layers in one launch (conv_igemm.hip).
+struct PackDesc {
+  const float* w; void* out;
+  int mode, tflip, Cout, Cin, RTot, RPad, KPad;
+  int blk0, nblk;
+  int64_t total;
+};
+static constexpr int PACK_MAX = 48;
+struct PackArgs { PackDesc d[PACK_MAX]; int n; };
+int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d);
+int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st);
+
 }  // namespace sx

@@ -194,12 +194,17 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ weight packing
+// out[tap][row][k] for every layer of a descriptor table (one launch packs the whole network)
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int tflip,
-                                   int Cout, int Cin, int ntaps, int RTot, int RPad, int KPad, int64_t total) {
-  // out[tap][row][k]
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+__global__ void pack_weight_kernel(PackArgs A) {
+  int di = 0;
+  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
+  const PackDesc& D = A.d[di];
+  const float* __restrict__ w = D.w;
+  T* __restrict__ out = reinterpret_cast<T*>(D.out);
+  const int mode = D.mode, tflip = D.tflip, Cout = D.Cout, Cin = D.Cin, RTot = D.RTot, RPad = D.RPad, KPad = D.KPad;
+  for (int64_t idx = ((int)blockIdx.x - D.blk0) * (int64_t)blockDim.x + threadIdx.x; idx < D.total;
+       idx += (int64_t)D.nblk * blockDim.x) {
     const int k = (int)(idx % KPad);
     const int64_t t2 = idx / KPad;
     const int row = (int)(t2 % RTot);
@@ -253,23 +258,43 @@ extern "C" int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c
   return (int64_t)ntaps * rtot * round_up(c_k, CK);
 }
 
-extern "C" int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
-                                   void* packed, void* stream) {
+namespace sx {
+int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d) {
   SX_REQUIRE(w && packed, "sx_pack_conv_weight: null pointer");
   SX_REQUIRE(mode >= SX_CONV3 && mode <= SX_CONVT_BWD, "sx_pack_conv_weight: bad mode %d", mode);
   SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_pack_conv_weight: bad dtype %d", dtype);
   PackGeom p = pack_geom(mode, dtype, transpose_flip, Cout, Cin);
-  const int64_t total = (int64_t)p.ntaps * p.RTot * p.KPad;
-  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 2048);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == SX_BF16)
-    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, (bf16*)packed, mode,
-                       transpose_flip, Cout, Cin, p.ntaps, p.RTot, p.RPad, p.KPad, total);
-  else
-    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)packed, mode,
-                       transpose_flip, Cout, Cin, p.ntaps, p.RTot, p.RPad, p.KPad, total);
-  SX_LAUNCH_CHECK("pack_weight");
+  d->w = w; d->out = packed; d->mode = mode; d->tflip = transpose_flip; d->Cout = Cout; d->Cin = Cin;
+  d->RTot = p.RTot; d->RPad = p.RPad; d->KPad = p.KPad;
+  d->total = (int64_t)p.ntaps * p.RTot * p.KPad;
+  d->blk0 = 0; d->nblk = 0;
   return SX_OK;
+}
+
+int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
+    PackArgs A;
+    A.n = std::min(PACK_MAX, n - i0);
+    int blk = 0;
+    for (int i = 0; i < A.n; ++i) {
+      A.d[i] = descs[i0 + i];
+      A.d[i].blk0 = blk;
+      A.d[i].nblk = (int)std::min<int64_t>(cdiv64(A.d[i].total, 256), 256);
+      blk += A.d[i].nblk;
+    }
+    if (dtype == SX_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blk), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blk), dim3(256), 0, st, A);
+    SX_LAUNCH_CHECK("pack_weight");
+  }
+  return SX_OK;
+}
+}  // namespace sx
+
+extern "C" int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
+                                   void* packed, void* stream) {
+  PackDesc d;
+  SX_TRY(pack_desc_fill(dtype, mode, transpose_flip, w, Cout, Cin, packed, &d));
+  return pack_weights_multi(dtype, &d, 1, (hipStream_t)stream);
 }
 
 extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin, int Cout,

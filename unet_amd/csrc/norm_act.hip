@@ -9,6 +9,8 @@
 // (and FiLM / dropout factors) are computed once into LDS.  Each thread owns a fixed 8-channel
 // slot and walks pixels: 16-byte bf16 / 2x16-byte fp32 accesses, fully coalesced in NHWC.
 #include "sx_common.h"
+#include "norm_act.h"
+#include <algorithm>
 
 namespace sx {
 
@@ -226,29 +228,48 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
   }
 }
 
-// dgamma[c] (+)= sum_b sums[b][c][0] ; dbeta[c] (+)= sum_b sums[b][c][1]
-// block = 64 channels x 4 batch lanes (fixed-order LDS combine)
-__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ sums, float* dgamma, float* dbeta, int B, int C,
-                                                            int accumulate) {
+// dgamma[c] (+)= sum_b sums[b][c][0] ; dbeta[c] (+)= sum_b sums[b][c][1]   for every GroupNorm of a descriptor table
+// block = 64 channels x 4 batch lanes (fixed-order LDS combine); one launch covers all layers of a backward half
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(GnGradArgs A) {
   __shared__ float red[2][4][64];
+  int di = 0;
+  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
+  const GnGradDesc& D = A.d[di];
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = ((int)blockIdx.x - D.blk0) * 64 + cl;
   float g = 0.f, bt = 0.f;
-  if (c < C)
-    for (int b = bl; b < B; b += 4) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(sums + ((int64_t)b * C + c) * 4);
+  if (c < D.C)
+    for (int b = bl; b < A.B; b += 4) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(D.sums + ((int64_t)b * D.C + c) * 4);
       g += v[0];
       bt += v[1];
     }
   red[0][bl][cl] = g;
   red[1][bl][cl] = bt;
   __syncthreads();
-  if (bl == 0 && c < C) {
+  if (bl == 0 && c < D.C) {
     g = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
     bt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-    dgamma[c] = accumulate ? dgamma[c] + g : g;
-    dbeta[c] = accumulate ? dbeta[c] + bt : bt;
+    D.dgamma[c] = A.accumulate ? D.dgamma[c] + g : g;
+    D.dbeta[c] = A.accumulate ? D.dbeta[c] + bt : bt;
   }
+}
+
+int gn_param_grad_multi(const GnGradDesc* descs, int n, int B, int accumulate, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += GN_GRAD_MAX) {
+    GnGradArgs A;
+    A.n = std::min(GN_GRAD_MAX, n - i0);
+    A.B = B; A.accumulate = accumulate;
+    int blk = 0;
+    for (int i = 0; i < A.n; ++i) {
+      A.d[i] = descs[i0 + i];
+      A.d[i].blk0 = blk;
+      blk += cdiv(A.d[i].C, 64);
+    }
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(blk), dim3(256), 0, st, A);
+    SX_LAUNCH_CHECK("gn_param_grad");
+  }
+  return SX_OK;
 }
 
 static int act_check(const ActArgs& a, const char* who) {
@@ -335,8 +356,9 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   else { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 0, grid, st, a); }
   SX_LAUNCH_CHECK("gn_bwd_apply");
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, sums, dgamma, dbeta, B, C, accumulate);
-    SX_LAUNCH_CHECK("gn_param_grad");
+    GnGradDesc d;
+    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0;
+    SX_TRY(gn_param_grad_multi(&d, 1, B, accumulate, st));
   }
   return SX_OK;
 }

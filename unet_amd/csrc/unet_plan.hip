@@ -11,6 +11,8 @@
 #include "sx_common.h"
 #include "film.h"
 #include "wgrad_common.h"
+#include "norm_act.h"
+#include "conv_common.h"
 #include <vector>
 
 namespace sx {
@@ -22,7 +24,7 @@ struct BlockBuf {   // byte offsets into the workspace
   int o_ld;
   int64_t st1, st2;                 // GN statistics [B][G][2] fp32
   int64_t gf, bf, pre, dpre;        // FiLM: [B][C] fp32 x2, [B][Hf] fp32 x2
-  int64_t dO, dY, dA1, dR;          // gradients (T)
+  int64_t dO, dY, dY1, dA1, dR;     // gradients (T); dY = d(conv2 out), dY1 = d(conv1 out)
   int64_t sums1, sums2;             // [B][C][4] fp32
   int64_t dX; int dx_ld;            // gradient w.r.t. the block input
   int Cin, Cin_real, C, H, W, G;
@@ -127,7 +129,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     b.Y1 = act(l, b.C); b.A1 = act(l, b.C); b.Y2 = act(l, b.C); b.S = act(l, b.C); b.R = act(l, b.C);
     if (k < D) { b.O = p.cat[l] + (int64_t)b.C * p.esz; b.o_ld = 2 * b.C; }
     else { b.O = act(l, b.C); b.o_ld = b.C; }
-    b.dO = act(l, b.C); b.dY = act(l, b.C); b.dA1 = act(l, b.C); b.dR = act(l, b.C);
+    b.dO = act(l, b.C); b.dY = act(l, b.C); b.dY1 = act(l, b.C); b.dA1 = act(l, b.C); b.dR = act(l, b.C);
     b.gf = take((int64_t)B * b.C * 4); b.bf = take((int64_t)B * b.C * 4);
     b.pre = take((int64_t)B * std::max(1, d.film_hidden) * 4); b.dpre = take((int64_t)B * std::max(1, d.film_hidden) * 4);
   }
@@ -230,14 +232,75 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   return film_backward(fa, wg, st);
 }
 
+// ---------------------------------------------------------------- side stream
+// Most launches of this network run 5-30 us on a 256-CU chip: launch ramp, first-touch latency and the store tail
+// are a large part of every kernel.  Work that is off the critical path (weight gradients, shortcut convolutions)
+// CAN be issued on a second stream to fill those bubbles (SX_SIDE=1|2|3); every entry point joins before it returns,
+// so callers still see single-stream semantics.  MEASURED on MI355X (cfg A, batch 64): 3.34 ms/step with either
+// use of the side stream against 3.23 ms without -- the persistent kernels own every CU while they run and the
+// cross-queue event waits cost more than the overlap returns -- so it is OFF by default.
+struct Side {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[32];
+  unsigned next = 0;
+  bool ok = false;
+};
+enum { SIDE_WGRAD = 1, SIDE_SHORTCUT = 2 };
+static Side* side_get(int what) {
+  static Side sides[16];
+  static const int enabled = getenv("SX_SIDE") ? atoi(getenv("SX_SIDE")) : 0;
+  if (!(enabled & what)) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Side& s = sides[dev];
+  if (!s.ok) {
+    if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (auto& e : s.ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.ok = true;
+  }
+  return &s;
+}
+// `to` waits for everything enqueued on `from` so far
+static int stream_after(Side* s, hipStream_t from, hipStream_t to) {
+  if (!s || from == to) return SX_OK;
+  hipEvent_t e = s->ev[s->next++ % 32];
+  hipError_t rc = hipEventRecord(e, from);
+  if (rc != hipSuccess) return hip_fail(rc, "hipEventRecord");
+  rc = hipStreamWaitEvent(to, e, 0);
+  if (rc != hipSuccess) return hip_fail(rc, "hipStreamWaitEvent");
+  return SX_OK;
+}
+
 // ---------------------------------------------------------------- weight-gradient queue
 // Every layer's split-K kernel writes its own slab; ONE fused launch reduces them all at the end of a backward half
 // (25 tiny reduce launches per step were ~8 % of the step).
 struct WgQueue {
-  char* base; int64_t cap, used; int dtype, B, acc; hipStream_t st;
+  char* base; int64_t cap, used; int dtype, B, acc;
+  hipStream_t main, st;          // st: where the weight-gradient kernels run (the side stream if there is one)
+  Side* side;
   std::vector<WgReduceDesc> pending;
-  WgQueue(const Plan& p, void* ws, int acc_, hipStream_t st_)
-      : base((char*)ws + p.wg_ws), cap(p.wg_ws_bytes), used(0), dtype(p.d.dtype), B(p.d.B), acc(acc_), st(st_) {}
+  std::vector<GnGradDesc> gn;      // GroupNorm affine gradients, reduced over the batch in one launch at the end
+  WgQueue(const Plan& p, void* ws, int acc_, hipStream_t main_)
+      : base((char*)ws + p.wg_ws), cap(p.wg_ws_bytes), used(0), dtype(p.d.dtype), B(p.d.B), acc(acc_), main(main_) {
+    side = side_get(SIDE_WGRAD);
+    st = side ? side->st : main_;
+  }
+  // what `main` has produced so far becomes visible to the weight-gradient stream
+  int fork() { return stream_after(side, main, st); }
+  // reduce everything pending and make `main` wait for it
+  int finish() {
+    SX_TRY(flush());
+    SX_TRY(stream_after(side, st, main));
+    if (!gn.empty()) SX_TRY(gn_param_grad_multi(gn.data(), (int)gn.size(), B, acc, main));
+    gn.clear();
+    return SX_OK;
+  }
+  void add_gn(const float* sums, float* dgamma, float* dbeta, int C) {
+    GnGradDesc d;
+    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0;
+    gn.push_back(d);
+  }
   int flush() {
     if (!pending.empty()) SX_TRY(wgrad_reduce_multi(pending.data(), (int)pending.size(), st));
     pending.clear();
@@ -265,13 +328,18 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
   const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
+  // the 1x1 shortcut only depends on the block input: it runs beside conv1 -> GN -> conv2 on the side stream
+  Side* side = side_get(SIDE_SHORTCUT);
+  hipStream_t ss = side ? side->st : st;
+  SX_TRY(stream_after(side, st, ss));
+  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
+                         at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, ss));
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.w1f), nullptr,
                          at(ws, b.Y1), b.C, b.H, b.W, 0, (float*)at(ws, b.st1), b.G, st));
   SX_TRY(sx_gn_silu_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1, at(ws, b.A1), b.C, st));
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.A1), b.C, b.H, b.W, at(wpack, b.w2f), nullptr,
                          at(ws, b.Y2), b.C, b.H, b.W, 0, (float*)at(ws, b.st2), b.G, st));
-  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
-                         at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, st));
+  SX_TRY(stream_after(side, ss, st));
   const bool keep_r = film || drop;
   SX_TRY(sx_block_out_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2, at(ws, b.S), b.C,
                               film ? (const float*)at(ws, b.gf) : nullptr, film ? (const float*)at(ws, b.bf) : nullptr, drop,
@@ -295,22 +363,27 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   SX_TRY(sx_gn_silu_backward(dt, 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                              at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
                              (float*)at(ws, b.sums2), at(ws, b.dY), b.C, keep_r ? at(ws, b.dR) : nullptr, b.C,
-                             wg ? grads[b.pidx + 4] : nullptr, wg ? grads[b.pidx + 5] : nullptr, acc, st));
+                             nullptr, nullptr, acc, st));
+  if (wg) wq.add_gn((const float*)at(ws, b.sums2), grads[b.pidx + 4], grads[b.pidx + 5], b.C);
   const void* dR = keep_r ? at(ws, b.dR) : at(ws, b.dO);
-  if (wg)
+  if (wg) {
+    SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
+  }
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w2d), nullptr,
                          at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
-  // through SiLU / GN1 (dY buffer is reused for dY1)
+  // through SiLU / GN1 (its own buffer: the weight-gradient stream may still be reading dY)
   SX_TRY(sx_gn_silu_backward(dt, 0, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
-                             at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY), b.C,
-                             nullptr, 0, wg ? grads[b.pidx + 1] : nullptr, wg ? grads[b.pidx + 2] : nullptr, acc, st));
+                             at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), b.C,
+                             nullptr, 0, nullptr, nullptr, acc, st));
+  if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
   if (wg) {
-    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY), b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
+    SX_TRY(wq.fork());
+    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY1), b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
     SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
   }
   if (need_dx) {
-    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
+    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
                            at(ws, b.dX), b.dx_ld, b.H, b.W, 0, nullptr, 0, st));
     SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, dR, b.C, b.H, b.W, at(wpack, b.wsd), nullptr,
                            at(ws, b.dX), b.dx_ld, b.H, b.W, 1, nullptr, 0, st));
@@ -375,22 +448,30 @@ extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* p
   SX_TRY(build_plan(d, p));
   SX_REQUIRE(params && wpack, "sx_unet_pack_weights: null pointer");
   const int dt = d->dtype;
+  std::vector<PackDesc> pk;
+  auto add = [&](int mode, int tflip, const float* w, int Cout, int Cin, void* out) {
+    PackDesc pd;
+    SX_TRY(pack_desc_fill(dt, mode, tflip, w, Cout, Cin, out, &pd));
+    pk.push_back(pd);
+    return (int)SX_OK;
+  };
   for (auto& b : p.blk) {
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 0, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1f), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 1, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1d), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 0, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2f), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV3, 1, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2d), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 0, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsf), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 1, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsd), stream));
+    SX_TRY(add(SX_CONV3, 0, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1f)));
+    SX_TRY(add(SX_CONV3, 1, params[b.pidx + 0], b.C, b.Cin_real, at(wpack, b.w1d)));
+    SX_TRY(add(SX_CONV3, 0, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2f)));
+    SX_TRY(add(SX_CONV3, 1, params[b.pidx + 3], b.C, b.C, at(wpack, b.w2d)));
+    SX_TRY(add(SX_CONV1, 0, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsf)));
+    SX_TRY(add(SX_CONV1, 1, params[b.pidx + 6], b.C, b.Cin_real, at(wpack, b.wsd)));
   }
   for (int j = 0; j < p.depth; ++j) {
     const int l = p.depth - 1 - j;
     // ConvTranspose2d weight is (Cin = C[l+1], Cout = C[l], 2, 2)
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONVT_FWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upf[j]), stream));
-    SX_TRY(sx_pack_conv_weight(dt, SX_CONVT_BWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upb[j]), stream));
+    SX_TRY(add(SX_CONVT_FWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upf[j])));
+    SX_TRY(add(SX_CONVT_BWD, 0, params[p.up_pidx[j]], p.C[l], p.C[l + 1], at(wpack, p.upb[j])));
   }
-  SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 0, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headf), stream));
-  SX_TRY(sx_pack_conv_weight(dt, SX_CONV1, 1, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headd), stream));
+  SX_TRY(add(SX_CONV1, 0, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headf)));
+  SX_TRY(add(SX_CONV1, 1, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headd)));
+  SX_TRY(pack_weights_multi(dt, pk.data(), (int)pk.size(), (hipStream_t)stream));
   SX_REQUIRE(p.out_pad <= 64, "sx_unet_pack_weights: out_ch %d too large", d->out_ch);
   hipLaunchKernelGGL(pad_bias_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params[p.out_pidx + 1], (float*)at(wpack, p.head_bias), d->out_ch, p.out_pad);
   SX_LAUNCH_CHECK("pad_bias");
@@ -443,7 +524,8 @@ extern "C" int sx_unet_decode(const sx_unet_desc* d, const float* const* params,
     const int l = D - 1 - j, k = D + 1 + j;
     const BlockBuf& prev = p.blk[k - 1];   // bottleneck for j = 0, else decoder j-1
     // h = up(h): ConvTranspose2d into channels [0, C_l) of the cat buffer; zero the F.pad strip
-    SX_TRY(sx_zero_border(dt, B, p.H[l], p.W[l], 2 * p.H[l + 1], 2 * p.W[l + 1], p.C[l], at(ws, p.cat[l]), 2 * p.C[l], stream));
+    if (p.H[l] != 2 * p.H[l + 1] || p.W[l] != 2 * p.W[l + 1])
+      SX_TRY(sx_zero_border(dt, B, p.H[l], p.W[l], 2 * p.H[l + 1], 2 * p.W[l + 1], p.C[l], at(ws, p.cat[l]), 2 * p.C[l], stream));
     SX_TRY(sx_conv_forward(dt, SX_CONVT_FWD, B, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld, p.H[l + 1], p.W[l + 1],
                            at(wpack, p.upf[j]), params[p.up_pidx[j] + 1], at(ws, p.cat[l]), 2 * p.C[l], p.H[l], p.W[l], 0, nullptr, 0, stream));
     SX_TRY(block_forward(p, k, params, wpack, ws, film, drop ? drop[j] : nullptr, st));
@@ -479,6 +561,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   // head
   const BlockBuf& last = p.blk[2 * D];
   if (wg) {
+    SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
                   at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
     float* db = grads[p.out_pidx + 1];
@@ -496,6 +579,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
       float* db = grads[p.up_pidx[j] + 1];
       if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)p.C[l] * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
       SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
+      SX_TRY(wq.fork());
       SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
                     at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]]));
     }
@@ -503,7 +587,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(sx_conv_forward(dt, SX_CONVT_BWD, B, p.H[l + 1], p.W[l + 1], p.C[l], p.C[l + 1], at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l],
                            at(wpack, p.upb[j]), nullptr, at(ws, prev.dO), p.C[l + 1], p.H[l + 1], p.W[l + 1], 0, nullptr, 0, stream));
   }
-  SX_TRY(wq.flush());
+  SX_TRY(wq.finish());
   if (film) SX_TRY(film_run_backward(p, D + 1, 2 * D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }
@@ -537,7 +621,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
                                     at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
     SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, wq, st));
   }
-  SX_TRY(wq.flush());
+  SX_TRY(wq.finish());
   if (film) SX_TRY(film_run_backward(p, 0, D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }
