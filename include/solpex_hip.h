@@ -186,7 +186,7 @@ int sx_masked_err_sums(int dtype, int denorm, int B, int C, int H, int W, const 
 int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
 int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float max_norm,
-                  const float* gnorm_sq, float grad_mul, float* gnorm_out, void* stream);
+                  const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-network entry points: UNet.encode / UNet.decode (models.py:173-203) and their backward,

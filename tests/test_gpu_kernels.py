@@ -385,15 +385,16 @@ def test_adamw_clip_matches_golden(L, golden):
     flat_p = torch.cat([p.reshape(-1) for p in ps]).cuda()
     m = torch.zeros_like(flat_p)
     v = torch.zeros_like(flat_p)
-    ss = torch.zeros(1, device="cuda")
+    ss = torch.zeros(2, device="cuda")       # two sum-of-squares slots: each step's kernel clears the next step's slot
     gn = torch.zeros(1, device="cuda")
     lib = L.lib()
     for step in range(3):
         flat_g = torch.cat([t(g[f"g{step}_{i}"]).reshape(-1) for i in range(n)]).cuda()
-        ss.zero_()
-        L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(ss), L.stream_ptr()))
+        cur, nxt = ss[step & 1:], ss[(step + 1) & 1:]
+        L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(cur), L.stream_ptr()))
         L.check(lib.sx_adamw_step(L.ptr(flat_p), L.ptr(flat_g), L.ptr(m), L.ptr(v), flat_p.numel(), float(g["lr"]), 0.9, 0.999,
-                                  1e-8, float(g["wd"]), step + 1, float(g["clip"]), L.ptr(ss), 1.0, L.ptr(gn), L.stream_ptr()))
+                                  1e-8, float(g["wd"]), step + 1, float(g["clip"]), L.ptr(cur), 1.0, L.ptr(gn), L.ptr(nxt),
+                                  L.stream_ptr()))
         torch.cuda.synchronize()
         assert abs(float(gn) - float(g[f"gnorm_{step}"])) < 1e-5 * float(g[f"gnorm_{step}"])
         off = 0

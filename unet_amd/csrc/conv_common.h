@@ -48,7 +48,7 @@ struct PackDesc {
   int blk0, nblk;
   int64_t total;
 };
-static constexpr int PACK_MAX = 48;
+static constexpr int PACK_MAX = 56;
 struct PackArgs { PackDesc d[PACK_MAX]; int n; };
 int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d);
 int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st);

@@ -55,10 +55,14 @@ __global__ __launch_bounds__(256) void film_bwd_a_kernel(FilmArgs a) {
 #pragma unroll
     for (int bb = 0; bb < FB; ++bb) s[bb] = 0.f;
     if (j < a.Hf)
-      for (int k = kp; k < K; k += 2) {
-        const float w = d.w2[(int64_t)k * a.Hf + j];
+      for (int k = kp; k < K; k += 16) {          // 8 independent loads in flight per thread (K is a multiple of 16)
+        float w[8];
 #pragma unroll
-        for (int bb = 0; bb < FB; ++bb) s[bb] += dout[bb][k] * w;
+        for (int u = 0; u < 8; ++u) w[u] = d.w2[(int64_t)(k + 2 * u) * a.Hf + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int bb = 0; bb < FB; ++bb) s[bb] += dout[bb][k + 2 * u] * w[u];
       }
 #pragma unroll
     for (int bb = 0; bb < FB; ++bb) part[kp][bb][jl] = s[bb];

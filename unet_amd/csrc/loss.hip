@@ -39,6 +39,12 @@ __device__ __forceinline__ void block_atomic_add(float (&v)[NV], float* dst) {
   }
 }
 
+// The scalar numerators are accumulated into NSLOT copies (one 128-byte line each, chosen by block index) and
+// summed by loss_final_kernel: 2048 blocks adding into ONE address serialise in the L2 (~13 ns per atomic, 90 us
+// for the base term alone), 32 adders per line do not.
+static constexpr int NSLOT = 64, SLOT_STRIDE = 32;
+__device__ __forceinline__ float* slot_of(float* num) { return num + (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE; }
+
 #define GRID_STRIDE(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 // NHWC T (ld) -> planar fp32 [B][C][H][W]
@@ -91,11 +97,12 @@ __global__ void avgpool_planar_kernel(const float* __restrict__ in, float* __res
 // den[0] += sum m ; den[1] += sum m*w   over (b, pixels)
 __global__ __launch_bounds__(256) void den_kernel(const float* __restrict__ m, const float* __restrict__ w, int B, int hw, float* den, int slot_m, int slot_w) {
   float v[2] = {0.f, 0.f};
-  const int64_t n = (int64_t)B * hw;
-  GRID_STRIDE(i, n) {
-    const float mm = m[i];
+  // grid.y = sample, grid.x = pixel chunks: no division per element, few blocks (the two sums end in atomics)
+  const float* mb = m + (int64_t)blockIdx.y * hw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+    const float mm = mb[i];
     v[0] += mm;
-    if (w) v[1] += mm * w[i % hw];
+    if (w) v[1] += mm * w[i];
   }
   __shared__ float red[8];
   block_sum<2>(v, red);
@@ -146,9 +153,10 @@ __global__ __launch_bounds__(256) void base_kernel(BaseArgs a) {
   __shared__ float red[12];
   block_sum<3>(v, red);
   if (threadIdx.x == 0) {
-    atomicAdd(a.num + 0, v[0]);
-    atomicAdd(a.num + 1, v[1]);
-    atomicAdd(a.num + 2, v[2]);
+    float* num = slot_of(a.num);
+    atomicAdd(num + 0, v[0]);
+    atomicAdd(num + 1, v[1]);
+    atomicAdd(num + 2, v[2]);
   }
 }
 
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void sobel_fwd_kernel(SobelArgs a) {
   }
   __shared__ float red[4];
   block_sum<1>(v, red);
-  if (threadIdx.x == 0) atomicAdd(a.num, v[0]);
+  if (threadIdx.x == 0) atomicAdd(slot_of(a.num), v[0]);
 }
 
 // transposed Sobel of (ux, uy) -> gradient at pooled resolution, spread over the ds x ds window of
@@ -261,22 +269,30 @@ __global__ void unpool2_add_kernel(const float* __restrict__ coarse, float* __re
 struct FinalArgs {
   const float* den; const float* num; const float* cw; int C;
   int nscales; float lam_w, lam_grad, ms_weight; int has_w;
-  float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = sum m (scale 0)
+  float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = out[3] = sum m (scale 0)
 };
 __global__ void loss_final_kernel(FinalArgs a) {
+  __shared__ float tot[16];
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int sl = 0; sl < NSLOT; ++sl) t += a.num[sl * SLOT_STRIDE + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
   if (threadIdx.x || blockIdx.x) return;
   const float scw = cw_sum(a.cw, a.C);
   float loss = 0.f;
   for (int s = 0; s < a.nscales; ++s) {
     const float coef = s == 0 ? 1.f : (s == 1 ? a.ms_weight : 0.5f * a.ms_weight);
-    float L = a.num[s * 4 + 0] / fmaxf(a.den[s * 3 + 0] * scw, 1e-8f);
-    if (a.has_w && a.lam_w != 0.f) L += a.lam_w * (a.num[s * 4 + 1] / fmaxf(a.den[s * 3 + 1] * scw, 1e-8f));
-    if (a.lam_grad != 0.f) L += a.lam_grad * (a.num[s * 4 + 3] / fmaxf(a.den[s * 3 + 2] * scw, 1e-8f));
+    float L = tot[s * 4 + 0] / fmaxf(a.den[s * 3 + 0] * scw, 1e-8f);
+    if (a.has_w && a.lam_w != 0.f) L += a.lam_w * (tot[s * 4 + 1] / fmaxf(a.den[s * 3 + 1] * scw, 1e-8f));
+    if (a.lam_grad != 0.f) L += a.lam_grad * (tot[s * 4 + 3] / fmaxf(a.den[s * 3 + 2] * scw, 1e-8f));
     loss += coef * L;
   }
   a.out[0] = loss;
-  a.out[1] = a.num[2];
+  a.out[1] = tot[2];
   a.out[2] = a.den[0];
+  a.out[3] = a.den[0];   // a DP caller overwrites this with its local pixel count (den is all-reduced by then)
 }
 
 // ---------------------------------------------------------------- workspace layout (floats)
@@ -296,7 +312,7 @@ static LossLayout loss_layout(int B, int C, int H, int W, int multiscale, int gr
   L.ns = 1 + std::max(0, std::min(multiscale, 2));
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
-  L.NUM = take(16);
+  L.NUM = take(NSLOT * SLOT_STRIDE);
   int gd = grad_ds < 1 ? 1 : grad_ds;
   for (int s = 0; s < L.ns; ++s) {
     L.h[s] = s == 0 ? H : L.h[s - 1] / 2;
@@ -354,7 +370,7 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
         hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz((int64_t)L.h[s] * L.w[s])), dim3(256), 0, st, w_prev, ws + L.Wm[s], (int64_t)1, L.h[s - 1], L.w[s - 1], 2, 0);
       }
     }
-    hipLaunchKernelGGL(den_kernel, dim3(gsz((int64_t)B * L.h[s] * L.w[s])), dim3(256), 0, st, m_s, w_s, B, L.h[s] * L.w[s], den, s * 3 + 0, s * 3 + 1);
+    hipLaunchKernelGGL(den_kernel, dim3(std::max(1, std::min(4, L.h[s] * L.w[s] / 1024)), B), dim3(256), 0, st, m_s, w_s, B, L.h[s] * L.w[s], den, s * 3 + 0, s * 3 + 1);
     if (lam_grad != 0.f) {
       if (L.gh[s] < 1 || L.gw[s] < 1) { set_error("sx_loss_prepare: grid too small for grad_ds"); return SX_ERR_UNSUPPORTED; }
       const float* mg = m_s;
@@ -362,7 +378,7 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
         hipLaunchKernelGGL(avgpool_planar_kernel, dim3(gsz((int64_t)B * L.gh[s] * L.gw[s])), dim3(256), 0, st, m_s, ws + L.MG[s], (int64_t)B, L.h[s], L.w[s], L.gds[s], 1);
         mg = ws + L.MG[s];
       }
-      hipLaunchKernelGGL(den_kernel, dim3(gsz((int64_t)B * L.gh[s] * L.gw[s])), dim3(256), 0, st, mg, (const float*)nullptr, B, L.gh[s] * L.gw[s], den, s * 3 + 2, -1);
+      hipLaunchKernelGGL(den_kernel, dim3(std::max(1, std::min(4, L.gh[s] * L.gw[s] / 1024)), B), dim3(256), 0, st, mg, (const float*)nullptr, B, L.gh[s] * L.gw[s], den, s * 3 + 2, -1);
     }
   }
   SX_LAUNCH_CHECK("loss_prepare");
@@ -371,7 +387,7 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
 
 // Phase 2.  pred: NHWC `dtype` tensor (ld); target: planar fp32 (B,C,H,W); den from phase 1 (possibly
 // all-reduced); same workspace as phase 1.  d_pred (NHWC dtype, ld) may be NULL (evaluation).
-// out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = sum mask.  grad_scale multiplies d_pred.
+// out (4 floats): out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = out[3] = sum mask.  grad_scale multiplies d_pred.
 extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld,
                                         const float* target, const float* mask, const float* w, const float* cw,
                                         int base_kind, float huber_beta, float lam_w, float lam_grad, int grad_magnitude,
@@ -384,7 +400,7 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
   LossLayout L = loss_layout(B, C, H, W, multiscale, grad_ds);
   float* ws = (float*)workspace;
   float* num = ws + L.NUM;
-  hipError_t e = hipMemsetAsync(num, 0, 16 * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(num, 0, NSLOT * SLOT_STRIDE * sizeof(float), st);
   if (e != hipSuccess) return hip_fail(e, "memset(num)");
   const bool want_grad = d_pred != nullptr;
   {

@@ -4,7 +4,9 @@
 
 namespace sx {
 
-struct GnGradDesc { const float* sums; float* dgamma; float* dbeta; int C, blk0; };   // sums: [B][C][4] fp32
+// sums: [nb][C][stride] fp32; element 0 -> dgamma, element 1 -> dbeta (dbeta may be null: bias gradients reuse the
+// launch with nb = 1, stride = 1).  nb = 0 means the launch's batch size.
+struct GnGradDesc { const float* sums; float* dgamma; float* dbeta; int C, blk0, nb, stride; };
 static constexpr int GN_GRAD_MAX = 32;
 struct GnGradArgs { GnGradDesc d[GN_GRAD_MAX]; int n, B, accumulate; };
 

@@ -238,11 +238,12 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GnGradArgs A) {
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
   const int c = ((int)blockIdx.x - D.blk0) * 64 + cl;
   float g = 0.f, bt = 0.f;
+  const int nb = D.nb > 0 ? D.nb : A.B;
   if (c < D.C)
-    for (int b = bl; b < A.B; b += 4) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(D.sums + ((int64_t)b * D.C + c) * 4);
+    for (int b = bl; b < nb; b += 4) {
+      const float* v = D.sums + ((int64_t)b * D.C + c) * D.stride;
       g += v[0];
-      bt += v[1];
+      if (D.dbeta) bt += v[1];
     }
   red[0][bl][cl] = g;
   red[1][bl][cl] = bt;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GnGradArgs A) {
     g = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
     bt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
     D.dgamma[c] = A.accumulate ? D.dgamma[c] + g : g;
-    D.dbeta[c] = A.accumulate ? D.dbeta[c] + bt : bt;
+    if (D.dbeta) D.dbeta[c] = A.accumulate ? D.dbeta[c] + bt : bt;
   }
 }
 
@@ -357,7 +358,7 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   SX_LAUNCH_CHECK("gn_bwd_apply");
   if (dgamma && dbeta) {
     GnGradDesc d;
-    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0;
+    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0; d.nb = 0; d.stride = 4;
     SX_TRY(gn_param_grad_multi(&d, 1, B, accumulate, st));
   }
   return SX_OK;

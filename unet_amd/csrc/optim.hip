@@ -24,6 +24,7 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
   float max_norm; const float* gnorm_sq; float grad_mul;
   float* gnorm_out;
+  float* clear_after;
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float gmul) {
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     if (a.max_norm > 0.f) gmul *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
     if (a.gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) a.gnorm_out[0] = norm;
   }
+  if (a.clear_after && blockIdx.x == 0 && threadIdx.x == 0) a.clear_after[0] = 0.f;
   const int64_t n4 = a.n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 p = *reinterpret_cast<f32x4*>(a.p + i * 4);
@@ -77,10 +79,11 @@ extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream
 // One AdamW step over a flat arena.  step is the 1-based step count.  If gnorm_sq != NULL the
 // gradients are first scaled by min(1, max_norm / (sqrt(gnorm_sq) * |grad_mul| + 1e-6)) (max_norm <= 0:
 // no clipping); grad_mul is a plain multiplier (e.g. 1/world_size, or 1/loss_scale).
-// gnorm_out (nullable) receives the pre-clip norm.
+// gnorm_out (nullable) receives the pre-clip norm.  clear_after (nullable, must not alias gnorm_sq) is set to 0 by
+// the kernel: callers that alternate between two sum-of-squares slots get the next step's slot zeroed for free.
 extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, float max_norm,
-                             const float* gnorm_sq, float grad_mul, float* gnorm_out, void* stream) {
+                             const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream) {
   SX_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "sx_adamw_step: bad arguments");
   SX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
              "sx_adamw_step: arenas must be 16-byte aligned");
@@ -90,7 +93,8 @@ extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  a.max_norm = max_norm; a.gnorm_sq = gnorm_sq; a.grad_mul = grad_mul; a.gnorm_out = gnorm_out;
+  a.max_norm = max_norm; a.gnorm_sq = gnorm_sq; a.grad_mul = grad_mul; a.gnorm_out = gnorm_out; a.clear_after = clear_after;
+  SX_REQUIRE(!clear_after || clear_after != gnorm_sq, "sx_adamw_step: clear_after must not alias gnorm_sq");
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 2048));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   SX_LAUNCH_CHECK("adamw_step");

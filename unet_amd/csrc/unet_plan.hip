@@ -44,6 +44,7 @@ struct Plan {
   std::vector<BlockBuf> blk;  // encoders 0..depth-1, bot (index depth), decoders (index depth+1+j)
   int64_t X0, cat[8], dcat[8], Pool[8], pred, dpred, dparams;
   int64_t stats_begin, stats_end, sums_begin, sums_end;
+  int64_t bias_scr[8], head_bias_scr, bwd_zero_end;   // bias-gradient scratch and dparams follow the decoder sums
   int64_t wg_ws; int64_t wg_ws_bytes;
   // convT / head packed weights and parameter indices
   int64_t upf[8], upb[8]; int up_pidx[8];
@@ -87,7 +88,6 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   }
   p.pred = act(0, p.out_pad);
   p.dpred = act(0, p.out_pad);
-  p.dparams = take((int64_t)B * std::max(1, d.P) * 4);
 
   p.blk.assign(2 * D + 1, BlockBuf());
   // parameter-table indices
@@ -147,6 +147,10 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   p.sums_begin = off;
   for (auto& b : p.blk) { b.sums1 = take((int64_t)B * b.C * 4 * 4); b.sums2 = take((int64_t)B * b.C * 4 * 4); }
   p.sums_end = off;
+  for (int j = 0; j < D; ++j) p.bias_scr[j] = take((int64_t)p.C[D - 1 - j] * 4);
+  p.head_bias_scr = take((int64_t)p.out_pad * 4);
+  p.bwd_zero_end = off;
+  p.dparams = take((int64_t)B * std::max(1, d.P) * 4);
   // wgrad slabs: every layer of a backward half keeps its own slab until the fused reduction at the end of the half
   // (WgQueue flushes early if it ever runs out, so this is a capacity, not a requirement)
   int64_t wgmax = 0;
@@ -298,7 +302,13 @@ struct WgQueue {
   }
   void add_gn(const float* sums, float* dgamma, float* dbeta, int C) {
     GnGradDesc d;
-    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0;
+    d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0; d.nb = 0; d.stride = 4;
+    gn.push_back(d);
+  }
+  // bias gradient: channel sums accumulated in workspace scratch (zeroed with the backward sums), copied / added here
+  void add_bias(const float* scratch, float* db, int C) {
+    GnGradDesc d;
+    d.sums = scratch; d.dgamma = db; d.dbeta = nullptr; d.C = C; d.blk0 = 0; d.nb = 1; d.stride = 1;
     gn.push_back(d);
   }
   int flush() {
@@ -549,13 +559,11 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
   {
+    // decoder sums, bias scratch and (optionally) dparams are contiguous: one memset
     const int64_t s0 = p.blk[D + 1].sums1;
-    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(p.sums_end - s0), st);
+    const int64_t s1 = (flags & SX_BWD_ZERO_DPARAMS) ? p.dparams + (int64_t)align_up((size_t)B * std::max(1, d->P) * 4, 256) : p.bwd_zero_end;
+    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(sums)");
-    if (flags & SX_BWD_ZERO_DPARAMS) {
-      e = hipMemsetAsync(at(ws, p.dparams), 0, (size_t)B * std::max(1, d->P) * 4, st);
-      if (e != hipSuccess) return hip_fail(e, "memset(dparams)");
-    }
   }
   WgQueue wq(p, ws, acc, st);
   // head
@@ -564,9 +572,8 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
                   at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
-    float* db = grads[p.out_pidx + 1];
-    if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)d->out_ch * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
-    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, db, stream));
+    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), stream));
+    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch);
   }
   SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], at(ws, p.dpred), p.out_pad, d->H, d->W, at(wpack, p.headd),
                          nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
@@ -576,9 +583,8 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     const BlockBuf& prev = p.blk[k - 1];
     const int Hs = 2 * p.H[l + 1], Ws = 2 * p.W[l + 1];
     if (wg) {
-      float* db = grads[p.up_pidx[j] + 1];
-      if (!acc) { hipError_t e = hipMemsetAsync(db, 0, (size_t)p.C[l] * 4, st); if (e != hipSuccess) return hip_fail(e, "memset(db)"); }
-      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], db, stream));
+      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), stream));
+      wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[l]);
       SX_TRY(wq.fork());
       SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
                     at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]]));

@@ -74,7 +74,7 @@ class LossBuffers:
         nbytes = L.check(lib.sx_loss_workspace_bytes(B, Cc, H, W, int(multiscale), int(grad_ds)))
         self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         self.den = torch.empty(9, dtype=torch.float32, device=device)
-        self.out = torch.empty(3, dtype=torch.float32, device=device)
+        self.out = torch.empty(4, dtype=torch.float32, device=device)    # loss, sum|p-t|*m, sum m, sum m
 
 
 def loss_prepare(bufs, B, Cc, H, W, mask, w, multiscale, grad_ds, lam_grad):
@@ -83,12 +83,13 @@ def loss_prepare(bufs, B, Cc, H, W, mask, w, multiscale, grad_ds, lam_grad):
 
 
 def loss_forward_backward(bufs, sx_dtype, B, Cc, H, W, pred, pred_ld, target, mask, w, cw, base, huber_beta, lam_w, lam_grad,
-                          grad_mode, grad_base, multiscale, ms_weight, grad_ds, d_pred, dpred_ld, grad_scale=1.0):
+                          grad_mode, grad_base, multiscale, ms_weight, grad_ds, d_pred, dpred_ld, grad_scale=1.0, out=None):
     L.check(L.lib().sx_loss_forward_backward(
         sx_dtype, B, Cc, H, W, L.ptr(pred), pred_ld, L.ptr(target), L.ptr(mask), L.ptr(w), L.ptr(cw),
         L.PX_KINDS[base], float(huber_beta), float(lam_w), float(lam_grad), 1 if grad_mode == "magnitude" else 0,
         L.PX_KINDS[grad_base], int(multiscale), float(ms_weight), int(grad_ds), L.ptr(bufs.den), L.ptr(bufs.ws),
-        L.ptr(bufs.out), L.ptr(d_pred), dpred_ld, float(grad_scale), L.stream_ptr()), "sx_loss_forward_backward")
+        L.ptr(bufs.out if out is None else out), L.ptr(d_pred), dpred_ld, float(grad_scale), L.stream_ptr()),
+        "sx_loss_forward_backward")
 
 
 class _LossFn(torch.autograd.Function):

@@ -89,7 +89,7 @@ class TrainEngine:
         if loss_opts:
             self.loss_opts.update(loss_opts)
         self._sessions = {}
-        self._ss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._ss = torch.zeros(2, dtype=torch.float32, device=self.device)   # ping-pong: the AdamW kernel clears the other slot
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.accum = 0
         # device-side per-batch log rows [loss, sum|p-t|*m, px (global under DP), px (local)], read once per epoch
@@ -146,17 +146,16 @@ class TrainEngine:
         pred = sess.view(L.SX_T_PRED)
         dpred = sess.view(L.SX_T_DPRED) if want_grad else None
         ld = pred.stride(3)
-        loss_forward_backward(bufs, self.sx_dtype, B, Cc, H, W, pred, ld, tgt, m, self.w_map, self.cw, o["base"],
-                              o["huber_beta"], o["lam_w"], o["lam_grad"], o["grad_mode"], o["grad_base"], o["multiscale"],
-                              o["ms_weight"], o["grad_ds"], dpred, ld, grad_scale)
-        out = bufs.out
         if self.nlog >= self.log.shape[0]:
             self.log = torch.cat([self.log, torch.zeros_like(self.log)])
-        row = self.log[self.nlog]
-        row[:3].copy_(out)
-        row[3:4].copy_(out[2:3] if px_local is None else px_local.reshape(1))
+        row = self.log[self.nlog]                       # [loss, sum|p-t|*m, sum m (global), sum m (local)]
+        loss_forward_backward(bufs, self.sx_dtype, B, Cc, H, W, pred, ld, tgt, m, self.w_map, self.cw, o["base"],
+                              o["huber_beta"], o["lam_w"], o["lam_grad"], o["grad_mode"], o["grad_base"], o["multiscale"],
+                              o["ms_weight"], o["grad_ds"], dpred, ld, grad_scale, out=row)
+        if px_local is not None:
+            row[3:4].copy_(px_local.reshape(1))
         self.nlog += 1
-        return out
+        return row[:3]
 
     # ------------------------------------------------------------------ steps
     def train_step(self, x, y, mask, params=None, *, lam_grad=None, grad_accum_steps=1, lr=None, step_now=True):
@@ -193,13 +192,14 @@ class TrainEngine:
         self.step_count += 1
         n = self.flat_p.numel()
         use_clip = bool(self.clip and self.clip > 0)
+        cur, nxt = self._ss[self.step_count & 1:], self._ss[(self.step_count + 1) & 1:]
         if use_clip:
-            self._ss.zero_()
-            L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(self._ss), L.stream_ptr()), "sx_grad_sumsq")
+            L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(cur), L.stream_ptr()), "sx_grad_sumsq")
         L.check(lib.sx_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n,
                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
-                                  self.step_count, float(self.clip) if use_clip else 0.0, L.ptr(self._ss) if use_clip else None,
-                                  1.0, L.ptr(self.gnorm) if use_clip else None, L.stream_ptr()), "sx_adamw_step")
+                                  self.step_count, float(self.clip) if use_clip else 0.0, L.ptr(cur) if use_clip else None,
+                                  1.0, L.ptr(self.gnorm) if use_clip else None, L.ptr(nxt) if use_clip else None,
+                                  L.stream_ptr()), "sx_adamw_step")
         self.accum = 0
 
     def flush(self, lr=None):
@@ -265,6 +265,7 @@ class TrainEngine:
             self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(float(st["step"]))
+            self._ss.zero_()          # both sum-of-squares slots clean whatever the new step parity is
 
 
 def train_unet(
