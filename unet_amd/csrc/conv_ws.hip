@@ -40,12 +40,15 @@ struct TilePos {
   }
 };
 
-template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF>
+// TWL: log2 of the tile width.  16-wide tiles: one MFMA pixel fragment = one tile row.  8-wide tiles (grids narrower
+// than 16, the deepest U-Net levels): a fragment = two rows of 8.
+template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF, int TWL>
 __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   constexpr int TAPW = TAPS == 9 ? 3 : 1;
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int BMC = WM * MI * 16;
-  constexpr int TH = WN * NI, TW = 16;
+  constexpr int TW = 1 << TWL, RPF = 16 / TW;      // rows per pixel fragment
+  constexpr int TH = WN * NI * RPF;
   constexpr int LW = TW + TAPW - 1, LH = TH + TAPW - 1;
   constexpr int NPIX = LH * LW, PIECES = NPIX * 4, NP = (PIECES + 255) / 256;
   constexpr int BUF = NP * 256 * 16;            // lane-linear image: piece p (pixel p>>2, part p&3) at byte 16*p
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     st_lx[q] = p < PIECES ? lx - PAD : -100000;
     st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + (p & 3) * 16;
   }
-  const int frag_off = (wn * NI * LW + n) * 64 + g * 16;
+  const int nr = n >> TWL, nc = n & (TW - 1);      // this lane's pixel inside a fragment
+  const int frag_off = ((wn * NI * RPF + nr) * LW + nc) * 64 + g * 16;
 
   TilePos ip;                     // issue position
   ip.set(t_begin, a.tiles_x, a.tiles_y);
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
   // epilogue addressing: lane (n, g) of frag (j, i) stores channels c0(j)..+3 of pixel (row wn*NI+i, column n)
   const int out_row = a.Wy * a.y_ld;
-  const int lane_out = (wn * NI * a.Wy + n) * a.y_ld + cb + wm * MI * 16 + 4 * g;
+  const int lane_out = ((wn * NI * RPF + nr) * a.Wy + nc) * a.y_ld + cb + wm * MI * 16 + 4 * g;
   f32x4 s1[MI], s2[MI];
 #pragma unroll
   for (int j = 0; j < MI; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
@@ -190,14 +194,14 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
       const char* buf = smem + (s % NBUF) * BUF + frag_off;
 #pragma unroll
-      for (int rr = 0; rr < NI + TAPW - 1; ++rr) {
+      for (int rr = 0; rr < NI * RPF + TAPW - 1; ++rr) {      // halo row of the fragments' first rows
         bf16x8 Bf[TAPW];
 #pragma unroll
         for (int tx = 0; tx < TAPW; ++tx) Bf[tx] = *reinterpret_cast<const bf16x8*>(buf + (rr * LW + tx) * 64);
 #pragma unroll
         for (int ty = 0; ty < TAPW; ++ty) {
-          const int i = rr - ty;
-          if (i >= 0 && i < NI) {
+          const int i = (rr - ty) / RPF;
+          if (rr - ty >= 0 && (rr - ty) % RPF == 0 && i < NI) {
 #pragma unroll
             for (int tx = 0; tx < TAPW; ++tx)
 #pragma unroll
@@ -210,16 +214,16 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
     // ---- epilogue of tile t = (cp.b, cp.ty, cp.tx)
     bf16* ytile = yg + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y_ld;   // wave-uniform
-    const bool xvalid = cp.tx * TW + n < a.W;
-    const int rows_left = a.H - cp.ty * TH - wn * NI;          // valid rows of this wave's NI rows
+    const bool xvalid = cp.tx * TW + nc < a.W;
+    const int rows_left = a.H - cp.ty * TH - wn * NI * RPF - nr;   // valid rows below this lane's first row
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const bool cvalid = cb + (wm * MI + j) * 16 + 4 * g < a.R;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         f32x4 v = acc[j][i];
-        if (cvalid && xvalid && i < rows_left) {
-          bf16* dst = ytile + (unsigned)(lane_out + i * out_row + j * 16);
+        if (cvalid && xvalid && i * RPF < rows_left) {
+          bf16* dst = ytile + (unsigned)(lane_out + i * RPF * out_row + j * 16);
           if (a.accumulate) v += load4(dst);
           store4(dst, v);
           if (do_stats) { s1[j] += v; s2[j] += v * v; }
@@ -233,15 +237,16 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
 }
 
-template <int KCH, int TAPS, int MI, int NI, int WM, int WN>
+template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int TWL = 4>
 static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int TAPW = TAPS == 9 ? 3 : 1;
-  constexpr int BMC = WM * MI * 16, TH = WN * NI, TW = 16;
+  constexpr int TW = 1 << TWL;
+  constexpr int BMC = WM * MI * 16, TH = WN * NI * (16 / TW);
   constexpr int NPIX = (TH + TAPW - 1) * (TW + TAPW - 1);
   constexpr int NP = (NPIX * 4 + 255) / 256;
   constexpr int NBUF = 4;                                       // three stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * 2 * sizeof(float);
-  auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF>;
+  auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -265,6 +270,14 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
 
 template <int KCH, int TAPS>
 static int ws_pick_tile(const ConvArgs& a, hipStream_t st) {
+  if (a.W < 16) {
+    // 8-wide tiles, 64 channels per block (grid.y = RTot/64): few pixels, many channels -- the deepest levels.
+    // 16-row tiles unless that leaves most of the chip without a block.
+    const int gy = cdiv(a.RTot, 64);
+    const int nt16 = a.B * cdiv(a.H, 16) * cdiv(a.W, 8);
+    if (nt16 * gy >= 256) return launch_ws<KCH, TAPS, 1, 8, 4, 1, 3>(a, st);
+    return launch_ws<KCH, TAPS, 1, 4, 4, 1, 3>(a, st);
+  }
   if (a.RTot <= 32) {
     if constexpr (KCH <= 4) return launch_ws<KCH, TAPS, 2, 4, 1, 4>(a, st);   // 32 ch x 256 px (16 rows)
     else return 1;
@@ -291,7 +304,7 @@ static int ws_pick_k(const ConvArgs& a, hipStream_t st) {
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), < 0 = error
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st) {
   if (mode != SX_CONV3 && mode != SX_CONV1) return 1;
-  if (a.W < 16 || a.bias || a.shuffle || a.R % 4) return 1;
+  if (a.W < 8 || a.bias || a.shuffle || a.R % 4) return 1;
   if (a.KPad % 32) return 1;
   return mode == SX_CONV3 ? ws_pick_k<9>(a, st) : ws_pick_k<1>(a, st);
 }
