@@ -83,6 +83,18 @@ int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin, int Cout,
                     void* stream);
 
 
+/* DoubleConv fusions (solpex/models.py:60-96: conv1 and the 1x1 shortcut read the same block input).
+ * sx_conv3_shortcut_forward: y = conv3x3(x, packed3) with GroupNorm statistics (as sx_conv_forward) and
+ *   s = conv1x1(x, packed1) in one pass over x (bf16 fast-path shapes; otherwise two launches, same results).
+ * sx_conv3_shortcut_dgrad: dx = conv3x3^T(dy) + conv1x1^T(dr) where dy = dyr[..., 0:C] and dr = dyr[..., C:2C] are the
+ *   channel halves of one NHWC buffer (leading dimension dyr_ld >= 2C); packed3_t / packed1_t are the
+ *   transpose_flip = 1 packs (rows = Cin of the forward convolution, K = C). */
+int sx_conv3_shortcut_forward(int dtype, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
+                              const void* packed3, const void* packed1, void* y, int y_ld, float* gn_stats,
+                              int gn_groups, void* s, int s_ld, void* stream);
+int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
+                            const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * sx_conv_wgrad: weight gradient as a split-K MFMA GEMM over pixels (weight half of
  * aten::convolution_backward for models.py:66,69,73-77,127,132).

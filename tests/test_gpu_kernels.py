@@ -96,6 +96,49 @@ def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     assert rel_err(from_nhwc(dx, Cin), dref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 8, 32), (2, 24, 16, 32, 64), (1, 16, 32, 64, 128), (3, 16, 8, 128, 256),
+                                             (1, 32, 16, 256, 128), (2, 16, 16, 128, 64), (2, 40, 16, 64, 32), (2, 16, 8, 256, 128),
+                                             (2, 13, 7, 16, 24), (1, 20, 12, 128, 128)])
+def test_conv3_shortcut_fused_forward_and_dgrad(L, dtype, B, H, W, Cin, Cout):
+    """DoubleConv fusions: conv1 + 1x1 shortcut from one pass over the input, and their joint data gradient from the
+    [dY1 | dR] buffer; shapes cover every tile configuration of the fused kernel variants and the unfused fallbacks."""
+    g = torch.Generator().manual_seed(B * 100 + H + Cin + Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w3 = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5), dtype)
+    w1 = q(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5, dtype)
+    xd = nhwc(x, dtype, ld=Cin + 8)
+    xd[..., Cin:] = 5.0
+    y = torch.empty(B, H, W, Cout, dtype=tdt(dtype), device="cuda")
+    sh = torch.full((B, H, W, Cout + 8), 7.0, dtype=tdt(dtype), device="cuda")
+    G = min(8, Cout)
+    stats = torch.zeros(B, G, 2, dtype=torch.float32, device="cuda")
+    p3 = pack(L, dtype, L.SX_CONV3, 0, w3, Cout, Cin, Cout, Cin)
+    p1 = pack(L, dtype, L.SX_CONV1, 0, w1, Cout, Cin, Cout, Cin)
+    L.check(L.lib().sx_conv3_shortcut_forward(dtype, B, H, W, Cin, Cout, L.ptr(xd), Cin + 8, L.ptr(p3), L.ptr(p1), L.ptr(y), Cout,
+                                              L.ptr(stats), G, L.ptr(sh), Cout + 8, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref3, ref1 = F.conv2d(x, w3, padding=1), F.conv2d(x, w1)
+    assert rel_err(from_nhwc(y, Cout), ref3) < TOL[dtype]
+    assert rel_err(from_nhwc(sh, Cout), ref1) < TOL[dtype]
+    assert float((sh[..., Cout:].float() - 7.0).abs().max()) == 0.0
+    rg = ref3.view(B, G, -1)
+    assert rel_err(stats.cpu(), torch.stack([rg.sum(-1), (rg * rg).sum(-1)], dim=-1)) < (1e-4 if dtype == 0 else 1e-2)
+    # joint data gradient
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    dr = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    dref = torch.nn.grad.conv2d_input(x.shape, w3, dy, padding=1) + torch.nn.grad.conv2d_input(x.shape, w1, dr)
+    dyr = torch.cat([nhwc(dy, dtype), nhwc(dr, dtype)], dim=-1).contiguous()
+    p3t = pack(L, dtype, L.SX_CONV3, 1, w3, Cout, Cin, Cin, Cout)
+    p1t = pack(L, dtype, L.SX_CONV1, 1, w1, Cout, Cin, Cin, Cout)
+    dx = torch.full((B, H, W, Cin + 8), 3.0, dtype=tdt(dtype), device="cuda")
+    L.check(L.lib().sx_conv3_shortcut_dgrad(dtype, B, H, W, Cout, Cin, L.ptr(dyr), 2 * Cout, L.ptr(p3t), L.ptr(p1t), L.ptr(dx), Cin + 8,
+                                            L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx, Cin), dref) < TOL[dtype]
+    assert float((dx[..., Cin:].float() - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Cin,Cout", [(32, 64), (128, 32), (256, 128), (64, 256)])
 def test_conv1x1_weights_stationary_accumulate(L, Cin, Cout):
     dtype, B, H, W = 1, 2, 24, 32

@@ -19,6 +19,9 @@ struct ConvArgs {
   int tw_log2, TW, TH, LW, LH;
   int tiles_x, tiles_y;
   int cpg;
+  // fused variants of the weights-stationary kernel (conv_ws.hip)
+  const void* w2;     // packed 1x1 weights: shortcut forward (second output) / shortcut dgrad (extra centre-tap K chunks)
+  void* y2; int y2_ld;
 };
 
 template <typename T> struct Mma;
@@ -39,7 +42,10 @@ template <> struct Mma<float> {
 
 
 // weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
-int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st);
+// var: 0 plain; WS_DUAL: y2 = conv1x1(x, w2) beside the 3x3 (same input tile); WS_CENTER: the input has 2K channels and
+// channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
+enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2 };
+int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
 
 // Weight packing for a whole table of layers in one launch (conv_igemm.hip).
 struct PackDesc {

@@ -352,3 +352,51 @@ extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin
   }
   return dtype == SX_BF16 ? conv_dispatch<bf16>(a, st) : conv_dispatch<float>(a, st);
 }
+
+// ------------------------------------------------------------------ DoubleConv fusions (models.py:60-96)
+// conv1 (3x3, + GroupNorm statistics) and the 1x1 shortcut read the same input: one pass over x on the fast path.
+extern "C" int sx_conv3_shortcut_forward(int dtype, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
+                                         const void* packed3, const void* packed1, void* y, int y_ld, float* gn_stats,
+                                         int gn_groups, void* s, int s_ld, void* stream) {
+  SX_REQUIRE(x && packed3 && packed1 && y && s, "sx_conv3_shortcut_forward: null pointer");
+  if (dtype == SX_BF16 && Cin % 8 == 0 && x_ld % 8 == 0 && Cout % 4 == 0 && y_ld % 4 == 0 && s_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
+      ((uintptr_t)x % 16) == 0 && ((uintptr_t)packed3 % 16) == 0 && ((uintptr_t)packed1 % 16) == 0 && ((uintptr_t)y % 8) == 0 &&
+      ((uintptr_t)s % 8) == 0 && (!gn_stats || (gn_groups > 0 && Cout % gn_groups == 0))) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = packed3; a.y = y; a.gn_stats = gn_stats; a.w2 = packed1; a.y2 = s; a.y2_ld = s_ld;
+    a.B = B; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.x_ld = x_ld; a.Hy = H; a.Wy = W; a.y_ld = y_ld;
+    a.K = Cin; a.KPad = round_up(Cin, 32);
+    a.R = Cout; a.RPad = round_up(Cout, 16); a.RTot = a.RPad;
+    a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1;
+    if (gn_stats) a.cpg = Cout / gn_groups;
+    const int rc = conv_ws_try(a, SX_CONV3, (hipStream_t)stream, WS_DUAL);
+    if (rc <= 0) return rc;
+  }
+  SX_TRY(sx_conv_forward(dtype, SX_CONV3, B, H, W, Cin, Cout, x, x_ld, H, W, packed3, nullptr, y, y_ld, H, W, 0, gn_stats, gn_groups, stream));
+  return sx_conv_forward(dtype, SX_CONV1, B, H, W, Cin, Cout, x, x_ld, H, W, packed1, nullptr, s, s_ld, H, W, 0, nullptr, 0, stream);
+}
+
+// dx = conv3x3^T(dy) + conv1x1^T(dr), dy = dyr[..., 0:C], dr = dyr[..., C:2C] (one buffer, leading dimension dyr_ld).
+// packed3_t / packed1_t: the transposed (+ flipped) packs, rows = Cin of the forward conv, K = C.
+extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
+                                       const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, void* stream) {
+  SX_REQUIRE(dyr && packed3_t && packed1_t && dx, "sx_conv3_shortcut_dgrad: null pointer");
+  SX_REQUIRE(dyr_ld >= 2 * C, "sx_conv3_shortcut_dgrad: dyr must hold 2*C channels per pixel");
+  if (dtype == SX_BF16 && C % 32 == 0 && dyr_ld % 8 == 0 && Cin % 4 == 0 && dx_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
+      ((uintptr_t)dyr % 16) == 0 && ((uintptr_t)packed3_t % 16) == 0 && ((uintptr_t)packed1_t % 16) == 0 && ((uintptr_t)dx % 8) == 0) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dyr; a.w = packed3_t; a.y = dx; a.w2 = packed1_t;
+    a.B = B; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.x_ld = dyr_ld; a.Hy = H; a.Wy = W; a.y_ld = dx_ld;
+    a.K = C; a.KPad = C;
+    a.R = Cin; a.RPad = round_up(Cin, 16); a.RTot = a.RPad;
+    a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1;
+    const int rc = conv_ws_try(a, SX_CONV3, (hipStream_t)stream, WS_CENTER);
+    if (rc <= 0) return rc;
+  }
+  const size_t esz = dtype == SX_BF16 ? 2 : 4;
+  SX_TRY(sx_conv_forward(dtype, SX_CONV3, B, H, W, C, Cin, dyr, dyr_ld, H, W, packed3_t, nullptr, dx, dx_ld, H, W, 0, nullptr, 0, stream));
+  return sx_conv_forward(dtype, SX_CONV1, B, H, W, C, Cin, (const char*)dyr + (size_t)C * esz, dyr_ld, H, W, packed1_t, nullptr, dx, dx_ld,
+                         H, W, 1, nullptr, 0, stream);
+}

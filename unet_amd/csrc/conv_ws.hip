@@ -42,7 +42,8 @@ struct TilePos {
 
 // TWL: log2 of the tile width.  16-wide tiles: one MFMA pixel fragment = one tile row.  8-wide tiles (grids narrower
 // than 16, the deepest U-Net levels): a fragment = two rows of 8.
-template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF, int TWL>
+// VAR: WS_PLAIN / WS_DUAL / WS_CENTER (conv_common.h): the 1x1 shortcut of a DoubleConv block rides along with the 3x3.
+template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF, int TWL, int VAR>
 __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   constexpr int TAPW = TAPS == 9 ? 3 : 1;
   constexpr int PAD = TAPS == 9 ? 1 : 0;
@@ -53,6 +54,9 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   constexpr int NPIX = LH * LW, PIECES = NPIX * 4, NP = (PIECES + 255) / 256;
   constexpr int BUF = NP * 256 * 16;            // lane-linear image: piece p (pixel p>>2, part p&3) at byte 16*p
   constexpr int DIST = NBUF - 1;                // stages in flight
+  constexpr int KTOT = VAR == WS_CENTER ? 2 * KCH : KCH;   // K chunks (= pipeline stages) per tile
+  constexpr int CT = TAPS / 2;                  // centre tap
+  static_assert(VAR == WS_PLAIN || TAPS == 9, "fused variants are 3x3 only");
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __align__(16) char smem[];
   float* sm_stat = reinterpret_cast<float*>(smem + NBUF * BUF);   // [WN][BMC][2]
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   const int t_begin = blockIdx.x * tpb;
   const int t_end = min(ntiles, t_begin + tpb);
   if (t_begin >= t_end) return;
-  const int nst = (t_end - t_begin) * KCH;
+  const int nst = (t_end - t_begin) * KTOT;
 
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(a.x);
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
@@ -87,6 +91,20 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg + ((int64_t)tap * a.RTot + row) * a.KPad + kc * 32 + g * 8);
         A[kc][tap][j] = v;
       }
+  // 1x1 weights of the fused variants: A2[kc][j] = W2[cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
+  bf16x8 A2[VAR == WS_PLAIN ? 1 : KCH][MI];
+  if constexpr (VAR != WS_PLAIN) {
+    const bf16* __restrict__ wg2 = reinterpret_cast<const bf16*>(a.w2);
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int row = cb + (wm * MI + j) * 16 + n;
+        bf16x8 v = {};
+        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg2 + (int64_t)row * a.KPad + kc * 32 + g * 8);
+        A2[kc][j] = v;
+      }
+  }
 
   // ---- staging: piece p = tid + q*256 -> halo pixel r = p>>2 (ly, lx), 16-byte part p&3.
   // Per image one buffer resource (num_records = image bytes): rows above / below the image fall outside it and
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + q * 4096), 16, off, 0, 0, 0);
     }
     ++is;
-    if (++ikc == KCH) { ikc = 0; ip.next(a.tiles_x, a.tiles_y); }
+    if (++ikc == KTOT) { ikc = 0; ip.next(a.tiles_x, a.tiles_y); }
   };
 
 #pragma unroll
@@ -136,6 +154,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   // epilogue addressing: lane (n, g) of frag (j, i) stores channels c0(j)..+3 of pixel (row wn*NI+i, column n)
   const int out_row = a.Wy * a.y_ld;
   const int lane_out = ((wn * NI * RPF + nr) * a.Wy + nc) * a.y_ld + cb + wm * MI * 16 + 4 * g;
+  const int out_row2 = a.Wy * a.y2_ld;
+  const int lane_out2 = ((wn * NI * RPF + nr) * a.Wy + nc) * a.y2_ld + cb + wm * MI * 16 + 4 * g;
   f32x4 s1[MI], s2[MI];
 #pragma unroll
   for (int j = 0; j < MI; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
@@ -180,19 +200,35 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   };
 
   for (int t = t_begin; t < t_end; ++t) {
-    f32x4 acc[MI][NI];
+    f32x4 acc[MI][NI], acc2[VAR == WS_DUAL ? MI : 1][VAR == WS_DUAL ? NI : 1];
 #pragma unroll
     for (int j = 0; j < MI; ++j)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NI; ++i) {
+        acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (VAR == WS_DUAL) acc2[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 
 #pragma unroll
-    for (int kc = 0; kc < KCH; ++kc, ++s) {
+    for (int kc = 0; kc < KTOT; ++kc, ++s) {
       wait_vmcnt<(DIST - 1) * NP>();                 // this wave's pieces of stage s have landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
       issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
       const char* buf = smem + (s % NBUF) * BUF + frag_off;
+      if constexpr (VAR == WS_CENTER) {
+        if (kc >= KCH) {                             // shortcut channels: centre tap only
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const bf16x8 Bc = *reinterpret_cast<const bf16x8*>(buf + ((i * RPF + 1) * LW + 1) * 64);
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[kc - KCH][j], Bc, acc[j][i], 0, 0, 0);
+          }
+          continue;
+        }
+      }
+      constexpr int KC = KCH;                        // bound for indexing A (kc < KCH here)
 #pragma unroll
       for (int rr = 0; rr < NI * RPF + TAPW - 1; ++rr) {      // halo row of the fragments' first rows
         bf16x8 Bf[TAPW];
@@ -206,7 +242,14 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
             for (int tx = 0; tx < TAPW; ++tx)
 #pragma unroll
               for (int j = 0; j < MI; ++j)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc][ty * TAPW + tx][j], Bf[tx], acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kc % KC][ty * TAPW + tx][j], Bf[tx], acc[j][i], 0, 0, 0);
+            if constexpr (VAR == WS_DUAL) {
+              if (ty == 1) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                  acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[kc % KC][j], Bf[1], acc2[j][i], 0, 0, 0);
+              }
+            }
           }
         }
       }
@@ -214,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
     // ---- epilogue of tile t = (cp.b, cp.ty, cp.tx)
     bf16* ytile = yg + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y_ld;   // wave-uniform
+    bf16* y2tile = VAR == WS_DUAL ? reinterpret_cast<bf16*>(a.y2) + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y2_ld : nullptr;
     const bool xvalid = cp.tx * TW + nc < a.W;
     const int rows_left = a.H - cp.ty * TH - wn * NI * RPF - nr;   // valid rows below this lane's first row
 #pragma unroll
@@ -227,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
           if (a.accumulate) v += load4(dst);
           store4(dst, v);
           if (do_stats) { s1[j] += v; s2[j] += v * v; }
+          if constexpr (VAR == WS_DUAL) store4(y2tile + (unsigned)(lane_out2 + i * RPF * out_row2 + j * 16), acc2[j][i]);
         }
       }
     }
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
 }
 
-template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int TWL = 4>
+template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int TWL, int VAR>
 static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int TAPW = TAPS == 9 ? 3 : 1;
   constexpr int TW = 1 << TWL;
@@ -246,7 +291,7 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int NP = (NPIX * 4 + 255) / 256;
   constexpr int NBUF = 4;                                       // three stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * 2 * sizeof(float);
-  auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL>;
+  auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL, VAR>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -268,45 +313,60 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   return SX_OK;
 }
 
-template <int KCH, int TAPS>
+template <int KCH, int TAPS, int VAR>
 static int ws_pick_tile(const ConvArgs& a, hipStream_t st) {
   if (a.W < 16) {
     // 8-wide tiles, 64 channels per block (grid.y = RTot/64): few pixels, many channels -- the deepest levels.
     // 16-row tiles unless that leaves most of the chip without a block.
     const int gy = cdiv(a.RTot, 64);
     const int nt16 = a.B * cdiv(a.H, 16) * cdiv(a.W, 8);
-    if (nt16 * gy >= 256) return launch_ws<KCH, TAPS, 1, 8, 4, 1, 3>(a, st);
-    return launch_ws<KCH, TAPS, 1, 4, 4, 1, 3>(a, st);
+    if constexpr (KCH == 8 && VAR == WS_DUAL) return 1;      // would spill: two launches instead
+    else {
+      if (nt16 * gy >= 256) return launch_ws<KCH, TAPS, 1, 8, 4, 1, 3, VAR>(a, st);
+      return launch_ws<KCH, TAPS, 1, 4, 4, 1, 3, VAR>(a, st);
+    }
   }
+  // register budget: the stationary weights take KCH*TAPS*MI*4 VGPRs (+ KCH*MI*4 for a fused 1x1), the accumulators
+  // MI*NI*4 (twice that with a second output); configurations that would spill use 16-channel wave tiles (MI = 1)
+  constexpr bool LIGHT = VAR == WS_DUAL && KCH >= 4;
   if (a.RTot <= 32) {
-    if constexpr (KCH <= 4) return launch_ws<KCH, TAPS, 2, 4, 1, 4>(a, st);   // 32 ch x 256 px (16 rows)
-    else return 1;
+    if constexpr (KCH > 4) return 1;
+    else if constexpr (LIGHT) return launch_ws<KCH, TAPS, 1, 4, 2, 2, 4, VAR>(a, st);   // 32 ch x 128 px
+    else return launch_ws<KCH, TAPS, 2, 4, 1, 4, 4, VAR>(a, st);                        // 32 ch x 256 px (16 rows)
   } else if (a.RTot <= 64) {
-    if constexpr (KCH <= 4) return launch_ws<KCH, TAPS, 2, 4, 2, 2>(a, st);   // 64 ch x 128 px (8 rows)
-    else return launch_ws<KCH, TAPS, 1, 8, 4, 1>(a, st);                      // 64 ch x 128 px
+    if constexpr (KCH <= 4 && !LIGHT) return launch_ws<KCH, TAPS, 2, 4, 2, 2, 4, VAR>(a, st);   // 64 ch x 128 px (8 rows)
+    else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                                // 64 ch x 128 px
   } else {
-    if constexpr (KCH <= 4) return launch_ws<KCH, TAPS, 2, 8, 4, 1>(a, st);   // 128 ch x 128 px
-    else return launch_ws<KCH, TAPS, 1, 8, 4, 1>(a, st);                      // 64 ch x 128 px, grid.y = RTot/64
+    if constexpr (KCH <= 4 && VAR == WS_PLAIN) return launch_ws<KCH, TAPS, 2, 8, 4, 1, 4, VAR>(a, st);   // 128 ch x 128 px
+    else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                      // 64 ch x 128 px, grid.y = RTot/64
   }
 }
 
-template <int TAPS>
+template <int TAPS, int VAR>
 static int ws_pick_k(const ConvArgs& a, hipStream_t st) {
   switch (a.KPad / 32) {
-    case 1: return ws_pick_tile<1, TAPS>(a, st);
-    case 2: return ws_pick_tile<2, TAPS>(a, st);
-    case 4: return ws_pick_tile<4, TAPS>(a, st);
-    case 8: return ws_pick_tile<8, TAPS>(a, st);
+    case 1: return ws_pick_tile<1, TAPS, VAR>(a, st);
+    case 2: return ws_pick_tile<2, TAPS, VAR>(a, st);
+    case 4: return ws_pick_tile<4, TAPS, VAR>(a, st);
+    case 8: return ws_pick_tile<8, TAPS, VAR>(a, st);
   }
   return 1;
 }
 
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), < 0 = error
-int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st) {
+int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
   if (mode != SX_CONV3 && mode != SX_CONV1) return 1;
   if (a.W < 8 || a.bias || a.shuffle || a.R % 4) return 1;
   if (a.KPad % 32) return 1;
-  return mode == SX_CONV3 ? ws_pick_k<9>(a, st) : ws_pick_k<1>(a, st);
+  if (var == WS_DUAL) {
+    if (mode != SX_CONV3 || a.accumulate || !a.w2 || !a.y2 || a.y2_ld % 4) return 1;
+    return ws_pick_k<9, WS_DUAL>(a, st);
+  }
+  if (var == WS_CENTER) {
+    if (mode != SX_CONV3 || !a.w2 || a.K % 32 || a.x_ld < 2 * a.K) return 1;
+    return ws_pick_k<9, WS_CENTER>(a, st);
+  }
+  return mode == SX_CONV3 ? ws_pick_k<9, WS_PLAIN>(a, st) : ws_pick_k<1, WS_PLAIN>(a, st);
 }
 
 }  // namespace sx

@@ -24,7 +24,8 @@ struct BlockBuf {   // byte offsets into the workspace
   int o_ld;
   int64_t st1, st2;                 // GN statistics [B][G][2] fp32
   int64_t gf, bf, pre, dpre;        // FiLM: [B][C] fp32 x2, [B][Hf] fp32 x2
-  int64_t dO, dY, dY1, dA1, dR;     // gradients (T); dY = d(conv2 out), dY1 = d(conv1 out)
+  int64_t dO, dY, dY1, dA1, dR;     // gradients (T); dY = d(conv2 out); dY1 = d(conv1 out) and dR = d(pre-FiLM sum) are the
+                                    // two channel halves of ONE [B,H,W,2C] buffer (fused conv1 + shortcut data gradient)
   int64_t sums1, sums2;             // [B][C][4] fp32
   int64_t dX; int dx_ld;            // gradient w.r.t. the block input
   int Cin, Cin_real, C, H, W, G;
@@ -129,7 +130,8 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     b.Y1 = act(l, b.C); b.A1 = act(l, b.C); b.Y2 = act(l, b.C); b.S = act(l, b.C); b.R = act(l, b.C);
     if (k < D) { b.O = p.cat[l] + (int64_t)b.C * p.esz; b.o_ld = 2 * b.C; }
     else { b.O = act(l, b.C); b.o_ld = b.C; }
-    b.dO = act(l, b.C); b.dY = act(l, b.C); b.dY1 = act(l, b.C); b.dA1 = act(l, b.C); b.dR = act(l, b.C);
+    b.dO = act(l, b.C); b.dY = act(l, b.C); b.dA1 = act(l, b.C);
+    b.dY1 = act(l, 2 * b.C); b.dR = b.dY1 + (int64_t)b.C * p.esz;
     b.gf = take((int64_t)B * b.C * 4); b.bf = take((int64_t)B * b.C * 4);
     b.pre = take((int64_t)B * std::max(1, d.film_hidden) * 4); b.dpre = take((int64_t)B * std::max(1, d.film_hidden) * 4);
   }
@@ -338,14 +340,20 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
   const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
-  // the 1x1 shortcut only depends on the block input: it runs beside conv1 -> GN -> conv2 on the side stream
+  // conv1 (+ GroupNorm statistics) and the 1x1 shortcut in one pass over the block input; with SX_SIDE=2 the shortcut
+  // runs as its own launch on the side stream instead
   Side* side = side_get(SIDE_SHORTCUT);
   hipStream_t ss = side ? side->st : st;
-  SX_TRY(stream_after(side, st, ss));
-  SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
-                         at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, ss));
-  SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.w1f), nullptr,
-                         at(ws, b.Y1), b.C, b.H, b.W, 0, (float*)at(ws, b.st1), b.G, st));
+  if (side) {
+    SX_TRY(stream_after(side, st, ss));
+    SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
+                           at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, ss));
+    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.w1f), nullptr,
+                           at(ws, b.Y1), b.C, b.H, b.W, 0, (float*)at(ws, b.st1), b.G, st));
+  } else {
+    SX_TRY(sx_conv3_shortcut_forward(dt, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, at(wpack, b.w1f), at(wpack, b.wsf),
+                                     at(ws, b.Y1), b.C, (float*)at(ws, b.st1), b.G, at(ws, b.S), b.C, st));
+  }
   SX_TRY(sx_gn_silu_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1, at(ws, b.A1), b.C, st));
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.A1), b.C, b.H, b.W, at(wpack, b.w2f), nullptr,
                          at(ws, b.Y2), b.C, b.H, b.W, 0, (float*)at(ws, b.st2), b.G, st));
@@ -372,10 +380,11 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   // through FiLM / dropout / residual / SiLU / GN2
   SX_TRY(sx_gn_silu_backward(dt, 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                              at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
-                             (float*)at(ws, b.sums2), at(ws, b.dY), b.C, keep_r ? at(ws, b.dR) : nullptr, b.C,
+                             (float*)at(ws, b.sums2), at(ws, b.dY), b.C, keep_r ? at(ws, b.dR) : nullptr, 2 * b.C,
                              nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums2), grads[b.pidx + 4], grads[b.pidx + 5], b.C);
   const void* dR = keep_r ? at(ws, b.dR) : at(ws, b.dO);
+  const int dr_ld = keep_r ? 2 * b.C : b.C;
   if (wg) {
     SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
@@ -384,19 +393,25 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
                          at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
   // through SiLU / GN1 (its own buffer: the weight-gradient stream may still be reading dY)
   SX_TRY(sx_gn_silu_backward(dt, 0, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
-                             at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), b.C,
+                             at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), 2 * b.C,
                              nullptr, 0, nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
   if (wg) {
     SX_TRY(wq.fork());
-    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY1), b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
-    SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
+    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY1), 2 * b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
+    SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, dr_ld, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
   }
   if (need_dx) {
-    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
-                           at(ws, b.dX), b.dx_ld, b.H, b.W, 0, nullptr, 0, st));
-    SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, dR, b.C, b.H, b.W, at(wpack, b.wsd), nullptr,
-                           at(ws, b.dX), b.dx_ld, b.H, b.W, 1, nullptr, 0, st));
+    if (keep_r) {
+      // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer
+      SX_TRY(sx_conv3_shortcut_dgrad(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
+                                     at(ws, b.dX), b.dx_ld, st));
+    } else {
+      SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
+                             at(ws, b.dX), b.dx_ld, b.H, b.W, 0, nullptr, 0, st));
+      SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, dR, dr_ld, b.H, b.W, at(wpack, b.wsd), nullptr,
+                             at(ws, b.dX), b.dx_ld, b.H, b.W, 1, nullptr, 0, st));
+    }
   }
   return SX_OK;
 }
