@@ -32,11 +32,12 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(FilmArgs a) {
 
 // phase A (grid = samples/8 x ngen): dpre[b][j] = (sum_k dout[b][k] W2[k][j]) * silu'(pre[b][j]);
 // dparams[b][p] += sum_j dpre[b][j] W1[j][p].  A block handles 4 samples so every W2 element it loads serves 4 FMAs;
-// threads = (hidden unit j) x (k parity), combined through LDS.
+// threads = (hidden unit j) x (k mod FKP), combined through LDS.
 static constexpr int FB = 4;
-__global__ __launch_bounds__(256) void film_bwd_a_kernel(FilmArgs a) {
+static constexpr int FKP = 8;        // threads that share one hidden unit (k is split FKP ways): 128 x FKP threads
+__global__ __launch_bounds__(1024) void film_bwd_a_kernel(FilmArgs a) {
   __shared__ float dout[FB][2 * 1024];
-  __shared__ float part[2][FB][128];
+  __shared__ float part[FKP][FB][128];
   __shared__ float dp[FB][128];
   const FilmGenDesc& d = a.g[blockIdx.y];
   const int b0 = blockIdx.x * FB, nb = min(FB, a.B - b0);
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(256) void film_bwd_a_kernel(FilmArgs a) {
 #pragma unroll
     for (int bb = 0; bb < FB; ++bb) s[bb] = 0.f;
     if (j < a.Hf)
-      for (int k = kp; k < K; k += 16) {          // 8 independent loads in flight per thread (K is a multiple of 16)
-        float w[8];
+      for (int k = kp; k < K; k += 16 * FKP) {    // 16 independent loads in flight per thread before the first FMA
+        float w[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = d.w2[(int64_t)(k + 2 * u) * a.Hf + j];
+        for (int u = 0; u < 16; ++u) w[u] = (k + FKP * u < K) ? d.w2[(int64_t)(k + FKP * u) * a.Hf + j] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
-          for (int bb = 0; bb < FB; ++bb) s[bb] += dout[bb][k + 2 * u] * w[u];
+          for (int bb = 0; bb < FB; ++bb) s[bb] += dout[bb][min(k + FKP * u, K - 1)] * w[u];
       }
 #pragma unroll
     for (int bb = 0; bb < FB; ++bb) part[kp][bb][jl] = s[bb];
@@ -71,7 +72,10 @@ __global__ __launch_bounds__(256) void film_bwd_a_kernel(FilmArgs a) {
       const int bb = i >> 7, jj = i & 127;
       float v = 0.f;
       if (bb < nb && j0 + jj < a.Hf) {
-        v = (part[0][bb][jj] + part[1][bb][jj]) * dsiluf_(d.pre[(int64_t)(b0 + bb) * a.Hf + j0 + jj]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < FKP; ++q) t += part[q][bb][jj];
+        v = t * dsiluf_(d.pre[(int64_t)(b0 + bb) * a.Hf + j0 + jj]);
         d.dpre[(int64_t)(b0 + bb) * a.Hf + j0 + jj] = v;
       }
       dp[bb][jj] = v;
@@ -176,7 +180,7 @@ int film_forward(const FilmArgs& a, hipStream_t st) {
 
 int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st) {
   if (a.ngen <= 0) return SX_OK;
-  hipLaunchKernelGGL(film_bwd_a_kernel, dim3(cdiv(a.B, FB), a.ngen), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(film_bwd_a_kernel, dim3(cdiv(a.B, FB), a.ngen), dim3(128 * FKP), 0, st, a);
   SX_LAUNCH_CHECK("film_bwd_a");
   if (weight_grads) {
     int cmax = 0;

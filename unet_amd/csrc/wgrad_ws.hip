@@ -347,7 +347,10 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
     const int tgc = tgk == 0 ? 1 : (tgk == 1 ? 3 : 9);
     const int tgh = tgk == 0 ? (p.taps == 9 ? 3 : 1) : 1, tgw = (tgk == 2 || p.taps == 1) ? 1 : 3;
     const int R = p.a_tiles * p.b_tiles * tgc;
-    int S = std::max(1, std::min(p.ntiles, 256 / R));
+    // at least MIN_TILES tiles per block: slab traffic (S slabs written, then read by the reduction) is what small-K
+    // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
+    const int min_tiles = getenv("SX_WG_MIN_TILES") ? atoi(getenv("SX_WG_MIN_TILES")) : 8;
+    int S = std::max(1, std::min(std::max(1, p.ntiles / min_tiles), 256 / R));
     const int tps = cdiv(p.ntiles, S);
     S = cdiv(p.ntiles, tps);
     const double halo = (double)(TH + tgh - 1) * (TW + tgw - 1) / (TH * TW);
