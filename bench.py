@@ -55,70 +55,74 @@ def make_model(seed=0):
 
 
 def conv_launches(B):
-    """(mode, Hc, Wc, Cin, Cout, flops) of every implicit-GEMM conv launch in one training step of cfg A:
-    fprop + dgrad of the 3x3 / 1x1 / transposed convs and the head (wgrad is a different kernel)."""
+    """Every launch of the dominant kernel (conv_ws_kernel, the weights-stationary implicit-GEMM convolution) in one
+    training step of cfg A: (kind, H, W, Cin, Cout, algorithmic flops).
+    kind: "dual" = conv1 3x3 + 1x1 shortcut forward (one launch), "c3"/"c1" = plain 3x3 / 1x1 (forward or data gradient),
+    "center" = joint data gradient of conv1 + shortcut.  Flops count the REAL channels (the 1-channel input is padded
+    to 8).  The transposed convolutions run in conv_igemm_kernel and the weight gradients in wgrad_ws_kernel."""
     C = [32, 64, 128, 256]
     Hs = [(128, 64), (64, 32), (32, 16), (16, 8)]
     out = []
 
-    def add(mode, hw, cin, cout, taps, n=1):
+    def block(hw, cin, cin_real, c, need_dx):
         h, w = hw
-        fl = 2.0 * B * h * w * cin * cout * taps
-        for _ in range(n):
-            out.append((mode, h, w, cin, cout, fl))
-    # encoder + bottleneck blocks: conv1, conv2, shortcut fprop; dgrad of conv2, conv1 + shortcut (not for block 0 input)
-    cin = 8   # packed input channels (1 real): algorithmic flops count the REAL channel
-    for l in range(4):
-        real_in = 1 if l == 0 else C[l - 1]
-        k_in = 8 if l == 0 else C[l - 1]
-        h, w = Hs[l]
-        out.append((0, h, w, k_in, C[l], 2.0 * B * h * w * real_in * C[l] * 9))
-        add(0, Hs[l], C[l], C[l], 9)
-        out.append((1, h, w, k_in, C[l], 2.0 * B * h * w * real_in * C[l]))
-        add(0, Hs[l], C[l], C[l], 9)                     # dgrad conv2
-        if l > 0:
-            add(0, Hs[l], C[l], C[l - 1], 9)             # dgrad conv1
-            add(1, Hs[l], C[l], C[l - 1], 1)             # dgrad shortcut
-    for l in (2, 1, 0):                                   # decoders
-        add(2, Hs[l + 1], C[l + 1], C[l], 4)             # convT fprop
-        add(0, Hs[l], 2 * C[l], C[l], 9)
-        add(0, Hs[l], C[l], C[l], 9)
-        add(1, Hs[l], 2 * C[l], C[l], 1)
-        add(0, Hs[l], C[l], C[l], 9)                     # dgrad conv2
-        add(0, Hs[l], C[l], 2 * C[l], 9)                 # dgrad conv1
-        add(1, Hs[l], C[l], 2 * C[l], 1)                 # dgrad shortcut
-        add(3, Hs[l + 1], C[l], C[l + 1], 4)             # convT dgrad
+        px = 2.0 * B * h * w
+        out.append(("dual", h, w, cin, c, px * cin_real * c * 10))        # conv1 + shortcut forward
+        out.append(("c3", h, w, c, c, px * c * c * 9))                     # conv2 forward
+        out.append(("c3", h, w, c, c, px * c * c * 9))                     # conv2 data gradient
+        if need_dx:
+            out.append(("center", h, w, c, cin, px * cin_real * c * 10))   # conv1 + shortcut data gradient
+    for l in range(4):                                                     # encoders + bottleneck
+        block(Hs[l], 8 if l == 0 else C[l - 1], 1 if l == 0 else C[l - 1], C[l], l > 0)
+    for l in (2, 1, 0):                                                    # decoders
+        block(Hs[l], 2 * C[l], 2 * C[l], C[l], True)
     h, w = Hs[0]
-    out.append((1, h, w, 32, 8, 2.0 * B * h * w * 32 * 8))   # head fprop
-    out.append((1, h, w, 8, 32, 2.0 * B * h * w * 32 * 8))   # head dgrad
-    return out
+    out.append(("c1", h, w, 8, 32, 2.0 * B * h * w * 32 * 8))             # head data gradient (the head's forward has a bias:
+    return out                                                            # conv_igemm_kernel)
 
 
 def measure_conv_roofline(B, sx_dtype, reps=5):
-    """Replay every conv launch of a step through sx_conv_forward between HIP events (torch events on the
-    stream the kernels are launched on).  Returns (total_flops, total_seconds, n_launches, total_bytes) where
-    total_bytes is the algorithmic HBM traffic (input image read once + output written once, packed weights)."""
+    """Replay every conv_ws_kernel launch of a step through the C ABI between HIP events (torch events on the stream the
+    kernels are launched on).  Returns (flops, seconds, launches, bytes): bytes = algorithmic HBM traffic (every input
+    tensor read once, every output written once, packed weights once)."""
     from unet_amd import _lib as L
     lib = L.lib()
     tdt = torch.bfloat16 if sx_dtype == L.SX_BF16 else torch.float32
     g = torch.Generator(device="cuda").manual_seed(0)
     total_fl, total_s, n, total_by = 0.0, 0.0, 0, 0.0
     st = torch.cuda.current_stream()
-    for (mode, h, w, cin, cout, fl) in conv_launches(B):
-        hx, wx, hy, wy = h, w, h, w
-        if mode == 2:
-            hy, wy = 2 * h, 2 * w
-        if mode == 3:
-            hx, wx = 2 * h, 2 * w
-        x = (torch.rand(B, hx, wx, cin, device="cuda", generator=g) - 0.5).to(tdt)
-        y = torch.empty(B, hy, wy, cout, device="cuda", dtype=tdt)
-        rows, k = cout, cin
-        nel = lib.sx_packed_weight_elems(mode, sx_dtype, rows, k)
-        wp = ((torch.rand(nel, device="cuda", generator=g) - 0.5) * 0.1).to(tdt)
-        stats = torch.zeros(B, 8, 2, device="cuda") if mode == 0 else None
-        def launch():
-            L.check(lib.sx_conv_forward(sx_dtype, mode, B, h, w, cin, cout, L.ptr(x), cin, hx, wx, L.ptr(wp), None, L.ptr(y),
-                                        cout, hy, wy, 0, L.ptr(stats), 8 if stats is not None else 0, L.stream_ptr()))
+
+    def rnd(*shape):
+        return (torch.rand(*shape, device="cuda", generator=g) - 0.5).to(tdt)
+
+    def packed(mode, rows, k):
+        return ((torch.rand(lib.sx_packed_weight_elems(mode, sx_dtype, rows, k), device="cuda", generator=g) - 0.5) * 0.1).to(tdt)
+
+    for (kind, h, w, cin, cout, fl) in conv_launches(B):
+        if kind == "dual":
+            x, y, s2 = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)
+            w3, w1 = packed(0, cout, cin), packed(1, cout, cin)
+            stats = torch.zeros(B, 8, 2, device="cuda")
+            tensors = (x, y, s2, w3, w1)
+            def launch():
+                L.check(lib.sx_conv3_shortcut_forward(sx_dtype, B, h, w, cin, cout, L.ptr(x), cin, L.ptr(w3), L.ptr(w1), L.ptr(y), cout,
+                                                      L.ptr(stats), 8, L.ptr(s2), cout, L.stream_ptr()))
+        elif kind == "center":
+            x, y = rnd(B, h, w, 2 * cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)
+            w3, w1 = packed(0, cout, cin), packed(1, cout, cin)
+            tensors = (x, y, w3, w1)
+            def launch():
+                L.check(lib.sx_conv3_shortcut_dgrad(sx_dtype, B, h, w, cin, cout, L.ptr(x), 2 * cin, L.ptr(w3), L.ptr(w1), L.ptr(y), cout,
+                                                    L.stream_ptr()))
+        else:
+            mode = 0 if kind == "c3" else 1
+            x, y = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)
+            wp = packed(mode, cout, cin)
+            stats = torch.zeros(B, 8, 2, device="cuda") if mode == 0 else None
+            tensors = (x, y, wp)
+            def launch():
+                L.check(lib.sx_conv_forward(sx_dtype, mode, B, h, w, cin, cout, L.ptr(x), cin, h, w, L.ptr(wp), None, L.ptr(y),
+                                            cout, h, w, 0, L.ptr(stats), 8 if stats is not None else 0, L.stream_ptr()))
         launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -128,9 +132,20 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
         e1.synchronize()
         total_s += e0.elapsed_time(e1) * 1e-3 / reps
         total_fl += fl
-        total_by += (x.numel() + y.numel() + wp.numel()) * x.element_size()
+        total_by += sum(t_.numel() * t_.element_size() for t_ in tensors)
         n += 1
     return total_fl, total_s, n, total_by
+
+
+def conv_traffic(a):
+    """HBM bytes per step of the same launches from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate
+    rocprofv3 --pmc runs of this file and committed under profiles/: tools/pmc_traffic.py).  Only valid for the
+    configuration it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_ws_traffic.json")
+    if a.batch != 64 or a.dtype != "bf16" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["hbm_bytes_per_step"])
 
 
 def cpu_baseline(batch, steps):
@@ -221,14 +236,16 @@ def main():
         sx_dtype = L.SX_BF16 if a.dtype == "bf16" else L.SX_F32
         if not a.no_roofline:
             fl, secs, n, nbytes = measure_conv_roofline(a.batch, sx_dtype)
-            peak = 2500.0 if a.dtype == "bf16" else 157.3
-            ach = fl / secs / 1e12
-            line["roofline"] = {"kernel": "conv_ws_kernel + conv_igemm_kernel (all fprop/dgrad launches of one step)",
-                                "bound": "mfma",
-                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                                "traffic": None, "launches_per_step": n, "flops_per_step": fl,
-                                "seconds_per_step": round(secs, 6),
-                                "hbm_algorithmic_GBps": round(nbytes / secs / 1e9, 1), "hbm_frac": round(nbytes / secs / 8e12, 4)}
+            mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3
+            tfs = fl / secs / 1e12
+            gbs = nbytes / secs / 1e9
+            # aggregate arithmetic intensity fl/nbytes (~180 flop/B) is below the machine balance (2.5 PF / 8 TB/s = 312):
+            # the family is bounded by HBM, so that is the roofline quoted; the MFMA view rides along
+            line["roofline"] = {"kernel": "conv_ws_kernel (every launch of one step: 3x3 / 1x1 forward and data gradients)",
+                                "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(gbs / 8000.0, 4), "traffic": conv_traffic(a), "launches_per_step": n,
+                                "bytes_per_step": nbytes, "flops_per_step": fl, "seconds_per_step": round(secs, 6),
+                                "mfma_TFLOPs": round(tfs, 2), "mfma_frac": round(tfs / mfma_peak, 4)}
             step_flops = 7.272e9 * a.batch
             line["step_model_tflops"] = round(step_flops * a.steps / dt / 1e12, 2)
         if not a.no_cpu_baseline:
