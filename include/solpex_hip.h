@@ -201,6 +201,21 @@ int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched inverse problems through the frozen network (scripts/eval_inverse_cycle_conditional_unet.py):
+ * every reference quantity that is per case (B = 1) is per SAMPLE here.
+ * sx_inverse_fit: weighted_masked_mse (:105-115) and masked_mae (:125-129) per sample + d fit / d pred.
+ *   pred NHWC `dtype` (pred_ld); target (B,C,H,W) fp32; mask (B,H,W) fp32; channel_weights[C] (0 for channels outside the
+ *   --fields selection); selected[C] (1/0, NULL = all) only affects mae.  fit[B], mae[B] (nullable), d_pred nullable.
+ * sx_inverse_adam_step: loss = fit + reg*mean(p^2) -> Adam -> clamp(+-clip) -> early-stop test, for every active sample
+ *   (:375-411; cosine learning rate `lr` for this step supplied by the caller, `step` is 1-based). */
+int sx_inverse_fit(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld, const float* target,
+                   const float* mask, const float* channel_weights, const float* selected, float* fit, float* mae,
+                   void* d_pred, int dpred_ld, float grad_scale, void* stream);
+int sx_inverse_adam_step(int N, int P, float* p, const float* grad, float* m, float* v, const float* fit, float lr,
+                         float beta1, float beta2, float eps, int step, float reg, float clip, int es_patience,
+                         float es_tol, float* best_loss, int* wait, int* active, float* loss_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Whole-network entry points: UNet.encode / UNet.decode (models.py:173-203) and their backward,
  * orchestrated in C++ so that a forward or backward pass is ONE call from the host language.
  *

@@ -120,3 +120,26 @@ def test_adamw_clip(golden):
             ps[i], ms[i], vs[i] = optim_ref.adamw_step(ps[i], gs[i], ms[i], vs[i], step + 1, float(g["lr"]),
                                                        weight_decay=float(g["wd"]))
             assert max_err(ps[i], g[f"p{step + 1}_{i}"]) < 1e-6
+
+
+def test_inverse_loop_matches_reference(golden):
+    """Per-case inverse loop (Adam + cosine, clamp, the reference's early-stop arithmetic) against the live-reference run."""
+    from oracle import inverse_ref
+    g = golden("inverse_case.npz")
+    cfg = cfg_from_golden(g)
+    sd = sd_from_golden(g, cfg)
+    mask, yt, p0 = t(g["mask"]), t(g["y_true_norm"]), t(g["p0"])
+    fidx = [int(i) for i in g["field_idx"]]
+    for patience in (0, 4):
+        for n in range(mask.shape[0]):
+            p, fit, mae, losses = inverse_ref.inverse_case(sd, cfg, mask[n:n + 1], yt[n:n + 1], p0[n:n + 1], fidx, t(g["cw_sel"]),
+                                                           steps=int(g["steps"]), lr=float(g["lr"]), reg=float(g["reg"]),
+                                                           clip=float(g["clip"]), patience=patience, tol=float(g["tol"]))
+            assert len(losses) == int(g[f"steps_run_p{patience}"][n])
+            ref_l = g[f"hist_p{patience}"][:len(losses), n]
+            assert np.allclose(losses, ref_l, rtol=2e-5, atol=1e-7)
+            assert np.allclose(p.numpy(), g[f"p_final_p{patience}"][n], rtol=0, atol=2e-5)
+            assert abs(fit - float(g[f"fit_p{patience}"][n])) < 2e-5 * abs(float(g[f"fit_p{patience}"][n]))
+            assert abs(mae - float(g[f"mae_p{patience}"][n])) < 2e-5 * abs(float(g[f"mae_p{patience}"][n]))
+    # the reference's early stop fires after exactly `patience` steps (rel_improv is NaN while best is inf)
+    assert [int(v) for v in g["steps_run_p4"]] == [4, 4, 4]

@@ -277,6 +277,76 @@ def train_case():
     save("train_history.npz", **arrs)
 
 
+def inverse_case():
+    """The per-case inverse loop of scripts/eval_inverse_cycle_conditional_unet.py (:332-416, Adam path) on the live
+    reference: the script's own module-level functions (weighted_masked_mse, masked_mae, build_x_from_mask) are imported;
+    the loop body, which lives inside its main(), is driven here statement by statement in the same order."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_inverse_script",
+                                                  "/root/reference/scripts/eval_inverse_cycle_conditional_unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=11)
+    model = ref_model(cfg, sd).eval()
+    N, H, W, steps, lr, reg, clip = 3, 16, 16, 12, 5e-2, 1e-4, 4.0
+    bt = make_batch(N, H, W, in_ch=1, out_ch=8, P=5, seed=4242, jitter_masks=True, empty_last=False)
+    mask = bt["mask"]                                   # (N,1,H,W)
+    p_true = bt["params"]
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        y_true_norm = model(mod.build_x_from_mask(mask), params=p_true) + 0.05 * torch.randn(N, 8, H, W, generator=g)
+    field_idx = [0, 1, 2, 4, 5, 7]
+    cw_sel = torch.tensor([1.0, 1.0, 0.5, 2.0, 0.25, 1.0])
+    p0 = 0.3 * torch.randn(N, 5, generator=g)
+    arrs = dict(cfg_dict(cfg))
+    arrs.update(mask=mask, y_true_norm=y_true_norm, p0=p0, field_idx=np.asarray(field_idx), cw_sel=cw_sel, steps=steps, lr=lr,
+                reg=reg, clip=clip, seed=11, sd_checksum=sd_checksum(sd), tol=1e-6)
+    for patience in (0, 4):
+        hist = np.full((steps, N), np.nan, dtype=np.float64)
+        p_fin, fit_fin, mae_fin, nrun = [], [], [], []
+        for n in range(N):
+            m_t = mask[n:n + 1]
+            y_sel = y_true_norm[n:n + 1][:, field_idx]
+            p_var = torch.nn.Parameter(p0[n:n + 1].clone())
+            opt = torch.optim.Adam([p_var], lr=lr)
+            sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps, eta_min=1e-5)
+            es_best, es_wait, ran = float("inf"), 0, 0
+            for step in range(steps):
+                x = mod.build_x_from_mask(m_t)
+                y_pred = model(x, params=p_var)
+                loss_fit = mod.weighted_masked_mse(y_pred[:, field_idx], y_sel, m_t, cw_sel)
+                loss = loss_fit + reg * (p_var ** 2).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                sched.step()
+                loss_item = float(loss.item())
+                with torch.no_grad():
+                    p_var.clamp_(-clip, clip)
+                hist[step, n] = loss_item
+                ran += 1
+                if patience > 0:
+                    rel_improv = (es_best - loss_item) / max(abs(es_best), 1e-12)
+                    if rel_improv > 1e-6:
+                        es_best, es_wait = loss_item, 0
+                    else:
+                        es_wait += 1
+                        if es_wait >= patience:
+                            break
+            with torch.no_grad():
+                y_pred = model(mod.build_x_from_mask(m_t), params=p_var)
+                fit_fin.append(float(mod.weighted_masked_mse(y_pred[:, field_idx], y_sel, m_t, cw_sel)))
+                mae_fin.append(float(mod.masked_mae(y_pred[:, field_idx], y_sel, m_t)))
+            p_fin.append(p_var.detach().numpy()[0].copy())
+            nrun.append(ran)
+        arrs.update({f"hist_p{patience}": hist, f"p_final_p{patience}": np.stack(p_fin), f"fit_p{patience}": np.asarray(fit_fin),
+                     f"mae_p{patience}": np.asarray(mae_fin), f"steps_run_p{patience}": np.asarray(nrun)})
+    for k, v in sd.items():
+        arrs["w::" + k] = v
+    save("inverse_case.npz", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     prod = dict(lam_grad=0.1, lam_w=0.5, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
@@ -294,7 +364,13 @@ def main():
     norm_cases()
     adamw_case()
     train_case()
+    inverse_case()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:               # regenerate only the named cases, e.g.  make_golden.py inverse_case
+        os.makedirs(OUT, exist_ok=True)
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()
