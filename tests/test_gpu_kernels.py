@@ -66,7 +66,9 @@ def pack(L, dtype, mode, tflip, w, Cout, Cin, rows, k):
                                              (1, 24, 16, 256, 256), (2, 40, 48, 8, 32), (1, 16, 16, 128, 64), (1, 32, 16, 64, 24),
                                              # 8-wide tiles of the same kernel (8 <= W < 16)
                                              (2, 16, 8, 128, 256), (1, 12, 10, 256, 64), (2, 9, 15, 32, 32), (5, 16, 8, 256, 256),
-                                             (70, 16, 8, 64, 128)])
+                                             (70, 16, 8, 64, 128),
+                                             # 512 input channels: two K halves, the second accumulating
+                                             (1, 16, 16, 512, 128), (2, 16, 8, 512, 256)])
 def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(B * 1000 + H + Cin)
     x = q(torch.randn(B, Cin, H, W, generator=g), dtype)

@@ -12,6 +12,7 @@ struct ConvArgs {
   int Hx, Wx, x_ld;
   int Hy, Wy, y_ld;
   int K, KPad;        // GEMM-K channels per tap (real / padded)
+  int KRow;           // row stride of the packed weights in elements (0 = KPad; set when a launch covers a K slice)
   int R, RPad, RTot;  // output channels (real / padded per tap group / rows per tap in `w`)
   int ntaps, tapw;
   int in_scale, pad;

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(a.y);
 
+  const int krow = a.KRow ? a.KRow : a.KPad;
   // ---- stationary weights: A[kc][tap][j] = W[tap][cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
   bf16x8 A[KCH][TAPS][MI];
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       for (int j = 0; j < MI; ++j) {
         const int row = cb + (wm * MI + j) * 16 + n;
         bf16x8 v = {};
-        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg + ((int64_t)tap * a.RTot + row) * a.KPad + kc * 32 + g * 8);
+        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg + ((int64_t)tap * a.RTot + row) * krow + kc * 32 + g * 8);
         A[kc][tap][j] = v;
       }
   // 1x1 weights of the fused variants: A2[kc][j] = W2[cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       for (int j = 0; j < MI; ++j) {
         const int row = cb + (wm * MI + j) * 16 + n;
         bf16x8 v = {};
-        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg2 + (int64_t)row * a.KPad + kc * 32 + g * 8);
+        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg2 + (int64_t)row * krow + kc * 32 + g * 8);
         A2[kc][j] = v;
       }
   }
@@ -365,6 +366,19 @@ int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
   if (var == WS_CENTER) {
     if (mode != SX_CONV3 || !a.w2 || a.K % 32 || a.x_ld < 2 * a.K) return 1;
     return ws_pick_k<9, WS_CENTER>(a, st);
+  }
+  if (a.KPad == 512 && a.K == 512) {
+    // 512 input channels do not fit the register-resident weight slice: two K halves, the second accumulating into the
+    // first one's output (GroupNorm statistics, if any, come from the second, i.e. from the complete sums)
+    ConvArgs h = a;
+    h.K = h.KPad = 256; h.KRow = 512; h.gn_stats = nullptr;
+    int rc = mode == SX_CONV3 ? ws_pick_k<9, WS_PLAIN>(h, st) : ws_pick_k<1, WS_PLAIN>(h, st);
+    if (rc != 0) return rc;
+    h.gn_stats = a.gn_stats;
+    h.x = reinterpret_cast<const bf16*>(a.x) + 256;
+    h.w = reinterpret_cast<const bf16*>(a.w) + 256;
+    h.accumulate = 1;
+    return mode == SX_CONV3 ? ws_pick_k<9, WS_PLAIN>(h, st) : ws_pick_k<1, WS_PLAIN>(h, st);
   }
   return mode == SX_CONV3 ? ws_pick_k<9, WS_PLAIN>(a, st) : ws_pick_k<1, WS_PLAIN>(a, st);
 }

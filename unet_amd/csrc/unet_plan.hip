@@ -380,11 +380,13 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   // through FiLM / dropout / residual / SiLU / GN2
   SX_TRY(sx_gn_silu_backward(dt, 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                              at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
-                             (float*)at(ws, b.sums2), at(ws, b.dY), b.C, keep_r ? at(ws, b.dR) : nullptr, 2 * b.C,
+                             (float*)at(ws, b.sums2), at(ws, b.dY), b.C, at(ws, b.dR), 2 * b.C,
                              nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums2), grads[b.pidx + 4], grads[b.pidx + 5], b.C);
-  const void* dR = keep_r ? at(ws, b.dR) : at(ws, b.dO);
-  const int dr_ld = keep_r ? 2 * b.C : b.C;
+  // dR = d(pre-FiLM sum) is always materialised next to dY1 (without FiLM / dropout it is a copy of dO): the joint
+  // conv1 + shortcut data gradient reads both from one buffer
+  const void* dR = at(ws, b.dR);
+  const int dr_ld = 2 * b.C;
   if (wg) {
     SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
@@ -402,16 +404,9 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
     SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, dr_ld, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
   }
   if (need_dx) {
-    if (keep_r) {
-      // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer
-      SX_TRY(sx_conv3_shortcut_dgrad(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
-                                     at(ws, b.dX), b.dx_ld, st));
-    } else {
-      SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, b.H, b.W, at(wpack, b.w1d), nullptr,
-                             at(ws, b.dX), b.dx_ld, b.H, b.W, 0, nullptr, 0, st));
-      SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.C, b.Cin, dR, dr_ld, b.H, b.W, at(wpack, b.wsd), nullptr,
-                             at(ws, b.dX), b.dx_ld, b.H, b.W, 1, nullptr, 0, st));
-    }
+    // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer
+    SX_TRY(sx_conv3_shortcut_dgrad(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
+                                   at(ws, b.dX), b.dx_ld, st));
   }
   return SX_OK;
 }
