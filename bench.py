@@ -113,7 +113,7 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
             tensors = (x, y, w3, w1)
             def launch():
                 L.check(lib.sx_conv3_shortcut_dgrad(sx_dtype, B, h, w, cin, cout, L.ptr(x), 2 * cin, L.ptr(w3), L.ptr(w1), L.ptr(y), cout,
-                                                    L.stream_ptr()))
+                                                    None, 0, L.stream_ptr()))
         else:
             mode = 0 if kind == "c3" else 1
             x, y = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)

@@ -88,12 +88,15 @@ int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin, int Cout,
  *   s = conv1x1(x, packed1) in one pass over x (bf16 fast-path shapes; otherwise two launches, same results).
  * sx_conv3_shortcut_dgrad: dx = conv3x3^T(dy) + conv1x1^T(dr) where dy = dyr[..., 0:C] and dr = dyr[..., C:2C] are the
  *   channel halves of one NHWC buffer (leading dimension dyr_ld >= 2C); packed3_t / packed1_t are the
- *   transpose_flip = 1 packs (rows = Cin of the forward convolution, K = C). */
+ *   transpose_flip = 1 packs (rows = Cin of the forward convolution, K = C).  ch_sum (nullable): ch_sum[c] += sum
+ *   over all pixels of dx[..., c] for c < ch_sum_n (fp32 atomics; caller zeroes) -- the bias gradient of the transposed
+ *   convolution whose output those channels are (models.py:190,200). */
 int sx_conv3_shortcut_forward(int dtype, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
                               const void* packed3, const void* packed1, void* y, int y_ld, float* gn_stats,
                               int gn_groups, void* s, int s_ld, void* stream);
 int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
-                            const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, void* stream);
+                            const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, float* ch_sum,
+                            int ch_sum_n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * sx_conv_wgrad: weight gradient as a split-K MFMA GEMM over pixels (weight half of

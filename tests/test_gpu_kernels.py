@@ -134,10 +134,14 @@ def test_conv3_shortcut_fused_forward_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     p3t = pack(L, dtype, L.SX_CONV3, 1, w3, Cout, Cin, Cin, Cout)
     p1t = pack(L, dtype, L.SX_CONV1, 1, w1, Cout, Cin, Cin, Cout)
     dx = torch.full((B, H, W, Cin + 8), 3.0, dtype=tdt(dtype), device="cuda")
+    nsum = Cin // 2 if (Cin // 2) % 8 == 0 else Cin        # channel sums of the first nsum output channels ride along
+    chs = torch.zeros(nsum, dtype=torch.float32, device="cuda")
     L.check(L.lib().sx_conv3_shortcut_dgrad(dtype, B, H, W, Cout, Cin, L.ptr(dyr), 2 * Cout, L.ptr(p3t), L.ptr(p1t), L.ptr(dx), Cin + 8,
-                                            L.stream_ptr()))
+                                            L.ptr(chs), nsum, L.stream_ptr()))
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(dx, Cin), dref) < TOL[dtype]
+    got = from_nhwc(dx, Cin)
+    assert rel_err(chs.cpu(), got[:, :nsum].sum(dim=(0, 2, 3))) < (1e-4 if dtype == 0 else 3e-3)
     assert float((dx[..., Cin:].float() - 3.0).abs().max()) == 0.0
 
 

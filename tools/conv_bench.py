@@ -28,7 +28,7 @@ for (kind, h, w, cin, cout, fl) in bench.conv_launches(B):
         x, y, w3, w1 = rnd(B, h, w, 2 * cin), rnd(B, h, w, cout), packed(0, cout, cin), packed(1, cout, cin)
         by = (x.numel() + y.numel()) * 2
         def launch():
-            L.check(lib.sx_conv3_shortcut_dgrad(1, B, h, w, cin, cout, L.ptr(x), 2 * cin, L.ptr(w3), L.ptr(w1), L.ptr(y), cout, L.stream_ptr()))
+            L.check(lib.sx_conv3_shortcut_dgrad(1, B, h, w, cin, cout, L.ptr(x), 2 * cin, L.ptr(w3), L.ptr(w1), L.ptr(y), cout, None, 0, L.stream_ptr()))
     else:
         mode = 0 if kind == "c3" else 1
         x, y, wp = rnd(B, h, w, cin), rnd(B, h, w, cout), packed(mode, cout, cin)

@@ -23,6 +23,7 @@ struct ConvArgs {
   // fused variants of the weights-stationary kernel (conv_ws.hip)
   const void* w2;     // packed 1x1 weights: shortcut forward (second output) / shortcut dgrad (extra centre-tap K chunks)
   void* y2; int y2_ld;
+  float* ch_sum; int ch_sum_n;   // optional: ch_sum[c] += sum over all output pixels of y[..., c], c < ch_sum_n (atomics)
 };
 
 template <typename T> struct Mma;

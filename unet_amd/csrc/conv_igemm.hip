@@ -379,8 +379,11 @@ extern "C" int sx_conv3_shortcut_forward(int dtype, int B, int H, int W, int Cin
 
 // dx = conv3x3^T(dy) + conv1x1^T(dr), dy = dyr[..., 0:C], dr = dyr[..., C:2C] (one buffer, leading dimension dyr_ld).
 // packed3_t / packed1_t: the transposed (+ flipped) packs, rows = Cin of the forward conv, K = C.
+// ch_sum (nullable): ch_sum[c] += sum over every pixel of dx[..., c] for c < ch_sum_n (fp32 atomics) -- when the block
+// input is a [transposed-conv output | skip] concatenation that IS the transposed convolution's bias gradient.
 extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
-                                       const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, void* stream) {
+                                       const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, float* ch_sum,
+                                       int ch_sum_n, void* stream) {
   SX_REQUIRE(dyr && packed3_t && packed1_t && dx, "sx_conv3_shortcut_dgrad: null pointer");
   SX_REQUIRE(dyr_ld >= 2 * C, "sx_conv3_shortcut_dgrad: dyr must hold 2*C channels per pixel");
   if (dtype == SX_BF16 && C % 32 == 0 && dyr_ld % 8 == 0 && Cin % 4 == 0 && dx_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
@@ -392,11 +395,17 @@ extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, in
     a.K = C; a.KPad = C;
     a.R = Cin; a.RPad = round_up(Cin, 16); a.RTot = a.RPad;
     a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1;
+    a.ch_sum = ch_sum; a.ch_sum_n = ch_sum ? ch_sum_n : 0;
     const int rc = conv_ws_try(a, SX_CONV3, (hipStream_t)stream, WS_CENTER);
     if (rc <= 0) return rc;
   }
   const size_t esz = dtype == SX_BF16 ? 2 : 4;
   SX_TRY(sx_conv_forward(dtype, SX_CONV3, B, H, W, C, Cin, dyr, dyr_ld, H, W, packed3_t, nullptr, dx, dx_ld, H, W, 0, nullptr, 0, stream));
-  return sx_conv_forward(dtype, SX_CONV1, B, H, W, C, Cin, (const char*)dyr + (size_t)C * esz, dyr_ld, H, W, packed1_t, nullptr, dx, dx_ld,
-                         H, W, 1, nullptr, 0, stream);
+  SX_TRY(sx_conv_forward(dtype, SX_CONV1, B, H, W, C, Cin, (const char*)dyr + (size_t)C * esz, dyr_ld, H, W, packed1_t, nullptr, dx, dx_ld,
+                         H, W, 1, nullptr, 0, stream));
+  if (ch_sum) {
+    SX_REQUIRE(ch_sum_n > 0 && ch_sum_n <= Cin && ch_sum_n % 8 == 0 && dx_ld % 8 == 0, "sx_conv3_shortcut_dgrad: bad channel-sum request");
+    SX_TRY(sx_channel_sum(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, stream));
+  }
+  return SX_OK;
 }

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < DIST; ++k) issue_stage();
   const bool do_stats = a.gn_stats != nullptr;
+  const bool do_chsum = a.ch_sum != nullptr;       // per-channel output sums (a bias gradient riding on a data gradient)
   int s = 0;
   TilePos cp;                     // compute position
   cp.set(t_begin, a.tiles_x, a.tiles_y);
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
           if (a.accumulate) v += load4(dst);
           store4(dst, v);
           if (do_stats) { s1[j] += v; s2[j] += v * v; }
+          else if (do_chsum) s1[j] += v;
           if constexpr (VAR == WS_DUAL) store4(y2tile + (unsigned)(lane_out2 + i * RPF * out_row2 + j * 16), acc2[j][i]);
         }
       }
@@ -279,6 +281,25 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     const int b_done = cp.b;
     cp.next(a.tiles_x, a.tiles_y);
     if (do_stats && (t + 1 == t_end || cp.b != b_done)) flush_stats(b_done);
+  }
+  if (do_chsum && !do_stats) {       // one flush per block: the sums run over every sample
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int cl = (wm * MI + j) * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = row_sum16(s1[j][r]);
+        if (n == 0) sm_stat[(wn * BMC + cl + r) * 2] = t1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < BMC && cb + tid < min(a.R, a.ch_sum_n)) {
+      float t1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) t1 += sm_stat[(w * BMC + tid) * 2];
+      atomicAdd(a.ch_sum + cb + tid, t1);
+    }
   }
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
 }

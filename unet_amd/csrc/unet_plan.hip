@@ -367,7 +367,8 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
 
 // d_out is read from b.dO.  Writes parameter gradients (if wg) and the input gradient into b.dX (if need_dx).
 static int block_backward(const Plan& p, int k, const float* const* params, float* const* grads, const void* wpack, void* ws,
-                          bool film, const float* drop, bool need_dx, int flags, WgQueue& wq, hipStream_t st) {
+                          bool film, const float* drop, bool need_dx, int flags, WgQueue& wq, hipStream_t st,
+                          float* ch_sum = nullptr, int ch_sum_n = 0) {
   const BlockBuf& b = p.blk[k];
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
@@ -406,7 +407,7 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   if (need_dx) {
     // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer
     SX_TRY(sx_conv3_shortcut_dgrad(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
-                                   at(ws, b.dX), b.dx_ld, st));
+                                   at(ws, b.dX), b.dx_ld, ch_sum, ch_sum_n, st));
   }
   return SX_OK;
 }
@@ -589,11 +590,16 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
                          nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
   for (int j = D - 1; j >= 0; --j) {
     const int l = D - 1 - j, k = D + 1 + j;
-    SX_TRY(block_backward(p, k, params, grads, wpack, ws, film, drop ? drop[j] : nullptr, true, flags, wq, st));
-    const BlockBuf& prev = p.blk[k - 1];
+    // the transposed conv's bias gradient = channel sums of the lower half of d(cat): they ride on the block's joint
+    // data gradient unless an F.pad strip (odd sizes) has to be left out of the sum
     const int Hs = 2 * p.H[l + 1], Ws = 2 * p.W[l + 1];
+    const bool ride = wg && Hs == p.H[l] && Ws == p.W[l];
+    SX_TRY(block_backward(p, k, params, grads, wpack, ws, film, drop ? drop[j] : nullptr, true, flags, wq, st,
+                          ride ? (float*)at(ws, p.bias_scr[j]) : nullptr, p.C[l]));
+    const BlockBuf& prev = p.blk[k - 1];
     if (wg) {
-      SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), stream));
+      if (!ride)
+        SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), stream));
       wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[l]);
       SX_TRY(wq.fork());
       SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
