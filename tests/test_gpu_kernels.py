@@ -184,7 +184,9 @@ def test_conv1x1_bias_accumulate_and_ld(L, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("B,h,w,Cin,Cout,Ho,Wo", [(2, 4, 4, 32, 16, 8, 8), (1, 3, 1, 16, 8, 7, 3), (2, 8, 4, 64, 32, 16, 8)])
+@pytest.mark.parametrize("B,h,w,Cin,Cout,Ho,Wo", [(2, 4, 4, 32, 16, 8, 8), (1, 3, 1, 16, 8, 7, 3), (2, 8, 4, 64, 32, 16, 8),
+                                                   (2, 16, 8, 256, 128, 32, 16), (3, 32, 16, 128, 64, 64, 32), (2, 64, 32, 64, 32, 128, 64),
+                                                   (1, 9, 17, 32, 16, 19, 35)])
 def test_conv_transpose_forward_and_backward(L, dtype, B, h, w, Cin, Cout, Ho, Wo):
     g = torch.Generator().manual_seed(h * 10 + Cin)
     x = q(torch.randn(B, Cin, h, w, generator=g), dtype)

@@ -262,6 +262,26 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     bf16* y2tile = VAR == WS_DUAL ? reinterpret_cast<bf16*>(a.y2) + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y2_ld : nullptr;
     const bool xvalid = cp.tx * TW + nc < a.W;
     const int rows_left = a.H - cp.ty * TH - wn * NI * RPF - nr;   // valid rows below this lane's first row
+    if (TAPS == 1 && VAR == WS_PLAIN && a.shuffle) {
+      // ConvTranspose2d(2,2) as four 1x1 GEMMs: row = tap*RPad + co, the output pixel of input pixel (y, x) under tap
+      // (ty, tx) is (2y + ty, 2x + tx); bias added here (models.py:190)
+      bf16* ybase = yg + ((int64_t)(cp.b * a.Hy + 2 * cp.ty * TH) * a.Wy + 2 * cp.tx * TW) * a.y_ld;
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int row = cb + (wm * MI + j) * 16 + 4 * g;
+        const int tp = row / a.RPad, co = row - tp * a.RPad;
+        if (row >= a.RTot || co >= a.R) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if (xvalid && i * RPF < rows_left) {
+            const int oy = 2 * (wn * NI * RPF + nr + i * RPF) + (tp >> 1), ox = 2 * nc + (tp & 1);
+            store4(ybase + (unsigned)((oy * a.Wy + ox) * a.y_ld + co), acc[j][i] + bv);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const bool cvalid = cb + (wm * MI + j) * 16 + 4 * g < a.R;
@@ -377,6 +397,12 @@ static int ws_pick_k(const ConvArgs& a, hipStream_t st) {
 
 // 0 = launched, 1 = not covered (caller falls back to the generic kernel), < 0 = error
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
+  if (mode == SX_CONVT_FWD) {
+    // four 1x1 GEMMs with a pixel-shuffle store (+ bias); bias needs 16-byte loads of 4 channels
+    if (var != WS_PLAIN || a.W < 8 || a.R % 4 || a.accumulate || a.gn_stats || a.KPad % 32 || a.KPad > 256) return 1;
+    if (a.bias && ((uintptr_t)a.bias % 16)) return 1;
+    return ws_pick_k<1, WS_PLAIN>(a, st);
+  }
   if (mode != SX_CONV3 && mode != SX_CONV1) return 1;
   if (a.W < 8 || a.bias || a.shuffle || a.R % 4) return 1;
   if (a.KPad % 32) return 1;
