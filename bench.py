@@ -137,6 +137,28 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
     return total_fl, total_s, n, total_by
 
 
+def measure_infer(model, x, p, dtype, steps, warmup, world, sync, dev):
+    """Forward-only throughput through the public module API (eval mode, packed weights cached)."""
+    model.eval()
+    model.compute_dtype = dtype
+    with torch.no_grad():
+        for _ in range(max(warmup, 2)):
+            model(x, params=p)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model(x, params=p)
+        sync()
+        dt = time.perf_counter() - t0
+    del y
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    model.train()
+    return world * x.shape[0] * steps / dt
+
+
 def conv_traffic(a):
     """HBM bytes per step of the same launches from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate
     rocprofv3 --pmc runs of this file and committed under profiles/: tools/pmc_traffic.py).  Only valid for the
@@ -222,6 +244,7 @@ def main():
         dt = float(tt)
     loss_last = float(eng.log[max(eng.nlog - 1, 0), 0])
     value = world * a.batch * a.steps / dt
+    infer = measure_infer(model, x, p, dtype, a.steps, a.warmup, world, sync, dev)
     line = {
         "metric": "train samples/s, cond. U-Net 128x64 grid (full training step)", "value": round(value, 2),
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -231,6 +254,9 @@ def main():
                                "(base 32, depth 3, P 5, out 8), huber+edge+Sobel loss, clip 1.0, AdamW",
                    "global_batch": world * a.batch, "grid": [H, W], "parallelism": f"dp{world}"},
         "final_loss": loss_last,
+        # the metric's "infer" half: UNet.forward (solpex/models.py:205-208) under no_grad, same batch / dtype, all ranks
+        "infer": {"value": round(infer, 2), "unit": "samples/s", "batch_per_gpu": a.batch,
+                  "what": "UNet.forward(x, params), eval mode, no_grad, inputs resident in HBM"},
     }
     if rank == 0:
         sx_dtype = L.SX_BF16 if a.dtype == "bf16" else L.SX_F32
