@@ -159,6 +159,15 @@ int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, f
 int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Device-resident dataset (replaces the per-item host path of SOLPSDataset.__getitem__ + default collate,
+ * data.py:359-391, for tensors that already live in HBM).
+ *   sx_gather_rows : dst[r][0..row_elems) = src[idx[r]][0..row_elems) for r < n_rows; idx is a DEVICE int64 array,
+ *                    strides in elements; out-of-range indices are skipped (the host wrapper raises IndexError first).
+ * --------------------------------------------------------------------------------------------- */
+int sx_gather_rows(const float* src, int64_t src_stride, int64_t n_src, const int64_t* idx, int n_rows, int64_t row_elems,
+                   float* dst, int64_t dst_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Mask-aware loss (losses.py:60-213), two phases so that data-parallel callers can all-reduce the
  * batch-global denominators in between.  Pixel-loss kinds: 0 huber (smooth L1), 1 l1, 2 mse.
  *   sx_loss_prepare: mask (B,1,H,W) fp32, w (H,W) fp32 or NULL -> den[9] = per scale

@@ -104,3 +104,27 @@ def test_dataset_and_loaders(tmp_path):
         D.SOLPSDataset(path, y_keys=["nope"])
     with pytest.raises(ValueError):
         D.make_loaders(path, y_keys=["Te"], device="cpu")
+
+
+def test_resident_loader_batch_order_mirrors_the_host_loader(tmp_path):
+    """ResidentLoader takes its batch order from torch's own DataLoader over positions: for one torch seed it is the
+    order of the reference's DataLoader(Subset(...), shuffle=True) (same RNG draws), checked here without a GPU."""
+    import torch
+    from torch.utils.data import DataLoader
+    from unet_amd import data as D
+    rng = np.random.default_rng(1)
+    N, H, W = 23, 8, 8
+    path = str(tmp_path / "d.npz")
+    np.savez(path, Te=np.abs(rng.normal(size=(N, H, W))).astype(np.float32), mask=np.ones((H, W), np.float32),
+             X=rng.normal(size=(N, 5)).astype(np.float32))
+    tl, vl, *_ = D.make_loaders(path, batch_size=4, device="cpu")          # host loaders
+    assert isinstance(tl, DataLoader)
+    torch.manual_seed(77)
+    host = [b["idx"].tolist() for b in tl] + [b["idx"].tolist() for b in tl]      # two epochs
+    torch.manual_seed(77)
+    pos = DataLoader(D._Positions(len(tl.dataset)), batch_size=4, shuffle=True)
+    ind = np.asarray(tl.dataset.indices)
+    mirror = [ind[b.numpy()].tolist() for b in pos] + [ind[b.numpy()].tolist() for b in pos]
+    assert host == mirror
+    with pytest.raises(RuntimeError):
+        D.ResidentLoader(tl.dataset, 4, True, "cpu")

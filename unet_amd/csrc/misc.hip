@@ -255,3 +255,38 @@ extern "C" int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, 
   SX_LAUNCH_CHECK("zero_border");
   return SX_OK;
 }
+
+// ------------------------------------------------------------------ batch assembly from a device-resident dataset
+// dst[r][0 .. row_elems) = src[idx[r]][0 .. row_elems): the collate step of a DataLoader over tensors that never leave
+// HBM (data.py:380-391 builds the same batch item by item on the host).  16-byte lanes when strides allow.
+namespace sx {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, const int64_t* __restrict__ idx,
+                                                          int64_t n_src, int64_t row_elems, float* __restrict__ dst, int64_t dst_stride, int vec) {
+  const int r = blockIdx.y;
+  const int64_t s = idx[r];
+  if (s < 0 || s >= n_src) return;          // host validates; never read out of bounds
+  const float* sp = src + s * src_stride;
+  float* dp = dst + (int64_t)r * dst_stride;
+  if (vec) {
+    const int64_t n4 = row_elems >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+      reinterpret_cast<f32x4*>(dp)[i] = reinterpret_cast<const f32x4*>(sp)[i];
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < row_elems; i += (int64_t)gridDim.x * blockDim.x) dp[i] = sp[i];
+  }
+}
+}  // namespace sx
+
+extern "C" int sx_gather_rows(const float* src, int64_t src_stride, int64_t n_src, const int64_t* idx, int n_rows, int64_t row_elems,
+                              float* dst, int64_t dst_stride, void* stream) {
+  SX_REQUIRE(src && idx && dst, "sx_gather_rows: null pointer");
+  SX_REQUIRE(n_rows >= 0 && n_rows <= 65535 && row_elems >= 0 && n_src > 0 && src_stride >= row_elems && dst_stride >= row_elems,
+             "sx_gather_rows: bad sizes (rows=%d row_elems=%lld)", n_rows, (long long)row_elems);
+  if (n_rows == 0 || row_elems == 0) return SX_OK;
+  const int vec = (row_elems % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) ? 1 : 0;
+  const int64_t work = vec ? row_elems / 4 : row_elems;
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(work, 256), 64));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, n_rows), dim3(256), 0, (hipStream_t)stream, src, src_stride, idx, n_src, row_elems, dst, dst_stride, vec);
+  SX_LAUNCH_CHECK("gather_rows");
+  return SX_OK;
+}

@@ -394,10 +394,104 @@ class SOLPSDataset(Dataset):
         return {"x": torch.cat(chans, dim=0), "y": y, "mask": mask, "params": params, "idx": int(idx)}
 
 
+class _Positions(Dataset):
+    """Positions 0..n-1: lets torch's own DataLoader / RandomSampler decide the batch order, so a ResidentLoader
+    consumes the global RNG exactly as the reference's DataLoader(shuffle=True) does (same permutations for a seed)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return int(i)
+
+
+class ResidentLoader:
+    """Device-resident replacement of `DataLoader(Subset(SOLPSDataset, indices), batch_size, shuffle)`.
+
+    The reference re-normalises every sample on the host every epoch (solpex/data.py:359-366) and collates item by
+    item; at the HIP path's step time that host loop is the bottleneck.  Here the subset is uploaded ONCE, normalised
+    ONCE on the device (sx_norm_apply), and a batch is three row gathers (sx_gather_rows) by a device index vector.
+    Yields the same dict (`x`, `y`, `mask`, `params`, `idx`) with the same values and the same batch order as the
+    host loader for a given torch seed; tensors are already on `device` (`idx` stays a host LongTensor).
+    """
+
+    def __init__(self, subset, batch_size, shuffle, device, drop_last=False, chunk=256):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("ResidentLoader needs a CUDA (ROCm) device; use the host DataLoader otherwise")
+        if isinstance(subset, Subset):
+            ds, indices = subset.dataset, np.asarray(subset.indices, dtype=np.int64)
+        else:
+            ds, indices = subset, np.arange(len(subset), dtype=np.int64)
+        if not isinstance(ds, SOLPSDataset):
+            raise TypeError("ResidentLoader wraps a SOLPSDataset (or a Subset of one)")
+        self.dataset, self.batch_size, self.device = subset, int(batch_size), device
+        self._order = DataLoader(_Positions(len(indices)), batch_size=batch_size, shuffle=shuffle, drop_last=drop_last)
+        self._indices = torch.from_numpy(indices)
+        n = len(indices)
+        self.n, self.C, self.H, self.W = n, ds.C_out, ds.H, ds.W
+        self.autoencoder = ds.inputs == "autoencoder"
+        mask = (ds.mask[indices] > 0.5).astype(np.float32)[:, None]                     # (n,1,H,W), data.py:369-370
+        self.mask = torch.from_numpy(mask).to(device)
+        self.y = torch.empty(n, self.C, self.H, self.W, dtype=torch.float32, device=device)
+        for i0 in range(0, n, chunk):
+            sel = indices[i0:i0 + chunk]
+            raw = ds.Y[sel][:, ds.ks] if ds._has_Y else ds.Te[sel][:, None]
+            raw = np.nan_to_num(np.ascontiguousarray(raw, dtype=np.float32), nan=0.0, posinf=0.0, neginf=0.0)
+            m = self.mask[i0:i0 + chunk]
+            if ds.normalizer is None:
+                self.y[i0:i0 + chunk] = torch.from_numpy(raw * mask[i0:i0 + chunk]).to(device)
+            else:
+                self.y[i0:i0 + chunk] = ds.normalizer.transform(torch.from_numpy(raw).to(device), m)
+        self.params = torch.from_numpy(np.ascontiguousarray(ds.params[indices], dtype=np.float32)).to(device)
+        self.P = self.params.shape[1]
+        self.geo = None
+        if not self.autoencoder and ds.Rn is not None:
+            self.geo = torch.from_numpy(np.stack([ds.Rn, ds.Zn]).astype(np.float32)).to(device).contiguous()
+        self.in_ch = self.C if self.autoencoder else (3 if self.geo is not None else 1)
+
+    def __len__(self):
+        return len(self._order)
+
+    def _gather(self, src, n_src, row, pos, nb, dst, dst_stride):
+        L.check(L.lib().sx_gather_rows(L.ptr(src), row, n_src, L.ptr(pos), nb, row, L.ptr(dst), dst_stride, L.stream_ptr()),
+                "sx_gather_rows")
+
+    def __iter__(self):
+        HW = self.H * self.W
+        for pos in self._order:                      # host LongTensor of positions inside the subset
+            nb = int(pos.numel())
+            if int(pos.min()) < 0 or int(pos.max()) >= self.n:
+                raise IndexError("ResidentLoader: sampler produced an index outside the subset")
+            pos_d = pos.to(self.device, non_blocking=True)
+            y = torch.empty(nb, self.C, self.H, self.W, dtype=torch.float32, device=self.device)
+            mask = torch.empty(nb, 1, self.H, self.W, dtype=torch.float32, device=self.device)
+            self._gather(self.y, self.n, self.C * HW, pos_d, nb, y, self.C * HW)
+            self._gather(self.mask, self.n, HW, pos_d, nb, mask, HW)
+            params = torch.empty(nb, self.P, dtype=torch.float32, device=self.device)
+            if self.P > 0:
+                self._gather(self.params, self.n, self.P, pos_d, nb, params, self.P)
+            if self.autoencoder:
+                x = y.clone()
+            elif self.geo is None:
+                x = mask.clone()
+            else:
+                x = torch.empty(nb, 3, self.H, self.W, dtype=torch.float32, device=self.device)
+                self._gather(self.mask, self.n, HW, pos_d, nb, x, 3 * HW)
+                zero = torch.zeros(nb, dtype=torch.int64, device=self.device)
+                self._gather(self.geo, 1, 2 * HW, zero, nb, x.view(nb, -1)[:, HW:], 3 * HW)
+            yield {"x": x, "y": y, "mask": mask, "params": params, "idx": self._indices[pos]}
+
+
 def make_loaders(npz_path, inputs_mode="params", batch_size=16, split=0.85, seed=42,
                  device="cuda" if torch.cuda.is_available() else "cpu", y_key="Te", y_keys=None, norm_fit_batch=16,
-                 geom_h5=None, norms_by_name=None, num_workers=0, param_transform=None):
-    """Reference: solpex/data.py:467-572.  Returns the same 8-tuple."""
+                 geom_h5=None, norms_by_name=None, num_workers=0, param_transform=None, resident=None):
+    """Reference: solpex/data.py:467-572.  Returns the same 8-tuple.  `resident` (extra): True = the two loaders are
+    `ResidentLoader`s (dataset held and normalised in HBM, batches gathered on the device); None = automatically when
+    `device` is a GPU and one is present; False = the reference's host DataLoaders."""
     geom = geom_h5 if inputs_mode != "autoencoder" else None
     kw = dict(geom_h5=geom, inputs=inputs_mode, y_key=y_key, y_keys=y_keys, param_transform=param_transform)
     raw_all = SOLPSDataset(npz_path, normalizer=None, **kw)
@@ -424,8 +518,14 @@ def make_loaders(npz_path, inputs_mode="params", batch_size=16, split=0.85, seed
     pin = torch.device(device).type == "cuda"
     extra = dict(num_workers=num_workers, pin_memory=pin, persistent_workers=(num_workers > 0),
                  prefetch_factor=(4 if num_workers > 0 else None))
-    train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, **extra)
-    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, **extra)
+    if resident is None:
+        resident = pin and torch.cuda.is_available()
+    if resident:
+        train_loader = ResidentLoader(train_set, batch_size, True, device)
+        val_loader = ResidentLoader(val_set, batch_size, False, device)
+    else:
+        train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, **extra)
+        val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, **extra)
     P = train_set.dataset.params.shape[1] if hasattr(train_set.dataset, "params") else 0
     H, W = train_set[0]["mask"].shape[-2:]
     return train_loader, val_loader, norm, P, (H, W), (param_mu, param_std), param_transform, raw_all.param_keys
