@@ -159,6 +159,29 @@ int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, f
 int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Latent MLPs (latent.py:14-48 ParamToZ / ZToParam and their SmoothL1 trainers, latent.py:51-310), fp32.
+ *   sx_gemm_f32 : C[m][n] (+)= epilogue( sum_k A(m,k) * B(n,k) + bias[n] ), A(m,k) = A[m*a_sm + k*a_sk],
+ *                 B(n,k) = B[n*b_sn + k*b_sk].  One kernel for nn.Linear forward (A = x, B = W), its input gradient
+ *                 (A = dy, B = W^T by strides) and its weight gradient (A = dy^T, B = x^T).  Epilogue, in this order:
+ *                 * mul[m][n] (dropout mask), * SiLU'(dact[m][n]), then if act: pre[m][n] = v, v = SiLU(v).
+ *                 rowsum (nullable): rowsum[m] (+)= sum_k A(m,k)  -- the bias gradient when A = dy^T.
+ *   sx_layernorm_forward / _backward : nn.LayerNorm over the last dimension; stats = [rows][mean, rstd];
+ *                 dgamma / dbeta accumulate (fp32 atomics; caller zeroes); dact (nullable) multiplies dx by SiLU'(dact).
+ *   sx_smooth_l1 : nn.SmoothL1Loss(beta), mean reduction: *out += mean; dpred (+)= grad_weight * dloss/dpred.
+ *   sx_mul       : y = x * m (nn.Dropout with a caller-drawn scaled mask).
+ * --------------------------------------------------------------------------------------------- */
+int sx_gemm_f32(int M, int N, int K, const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sn, int64_t b_sk,
+                float* C, int64_t ldc, const float* bias, int act, float* pre, int64_t ld_pre, const float* mul,
+                int64_t ld_mul, const float* dact, int64_t ld_dact, float* rowsum, int accumulate, void* stream);
+int sx_layernorm_forward(int rows, int N, const float* x, const float* gamma, const float* beta, float eps, float* y,
+                         float* stats, void* stream);
+int sx_layernorm_backward(int rows, int N, const float* x, const float* gamma, const float* stats, const float* dy,
+                          float* dx, float* dgamma, float* dbeta, const float* dact, void* stream);
+int sx_smooth_l1(int64_t n, const float* pred, const float* target, float beta, float* out, float* dpred,
+                 float grad_weight, int accumulate, void* stream);
+int sx_mul(int64_t n, const float* x, const float* m, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Device-resident dataset (replaces the per-item host path of SOLPSDataset.__getitem__ + default collate,
  * data.py:359-391, for tensors that already live in HBM).
  *   sx_gather_rows : dst[r][0..row_elems) = src[idx[r]][0..row_elems) for r < n_rows; idx is a DEVICE int64 array,

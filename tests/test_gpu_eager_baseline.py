@@ -85,3 +85,57 @@ def test_hip_step_is_faster_than_eager_torch_on_the_same_gpu():
     print(res)
     for name in res:
         assert res[name]["hip_ms"] < res[name]["eager_torch_ms"], res
+
+
+def test_latent_cycle_trainer_step_vs_eager_torch_on_the_same_gpu():
+    """train_cycle_consistent's step (two 256-wide MLPs, batch 64, z_dim 256, P 5): HIP kernels vs the oracle in eager
+    PyTorch on the same GPU.  Both are launch-latency bound; recorded in gpurun_out/eager_baseline_latent.json."""
+    from oracle import latent_ref
+    from unet_amd import latent as HL
+    rng = __import__("numpy").random.default_rng(0)
+    N, zd, Pd, bs = 64 * 40, 256, 5, 64
+    Z = rng.normal(size=(N, zd)).astype("float32")
+    P = rng.normal(size=(N, Pd)).astype("float32")
+    torch.manual_seed(0)
+    p2z, z2p = HL.ParamToZ(Pd, zd), HL.ZToParam(zd, Pd)
+    sd_a = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in p2z.state_dict().items()}
+    sd_b = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in z2p.state_dict().items()}
+    opt = latent_ref._Opt([sd_a, sd_b], 1e-3, 1e-4)
+    Zd, Pdv = torch.from_numpy(Z).cuda(), torch.from_numpy(P).cuda()
+
+    def eager_epoch():
+        for i in range(0, N, bs):
+            z, p = Zd[i:i + bs], Pdv[i:i + bs]
+            t0_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_b, z), p)
+            t1_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_a, p), z)
+            t2_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_b, latent_ref.mlp_forward(sd_a, p)), p)
+            t3_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_a, latent_ref.mlp_forward(sd_b, z)), z)
+            (t0_ + t1_ + 0.1 * (t2_ + t3_)).backward()
+            opt.step()
+    eager_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eager_epoch()
+    torch.cuda.synchronize()
+    eager_us = 1e6 * (time.perf_counter() - t0) / (N // bs)
+
+    p2z, z2p = p2z.cuda(), z2p.cuda()
+    eng = HL._Trainer([p2z, z2p], 1e-3, 1e-4, torch.device("cuda"))
+
+    def hip_epoch():
+        for i in range(0, N, bs):
+            HL._cycle_losses(eng, p2z, z2p, Zd[i:i + bs], Pdv[i:i + bs], 0.1, True)
+            eng.step()
+        eng.read()
+    hip_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hip_epoch()
+    torch.cuda.synchronize()
+    hip_us = 1e6 * (time.perf_counter() - t0) / (N // bs)
+    res = {"workload": "train_cycle_consistent step, batch 64, z_dim 256, P 5, hidden (256,256)",
+           "eager_torch_us_per_step": round(eager_us, 1), "hip_us_per_step": round(hip_us, 1)}
+    with open(os.path.join(ROOT, "gpurun_out", "eager_baseline_latent.json"), "w") as f:
+        json.dump(res, f)
+    print(res)
+    assert hip_us < eager_us, res

@@ -143,3 +143,44 @@ def test_inverse_loop_matches_reference(golden):
             assert abs(mae - float(g[f"mae_p{patience}"][n])) < 2e-5 * abs(float(g[f"mae_p{patience}"][n]))
     # the reference's early stop fires after exactly `patience` steps (rel_improv is NaN while best is inf)
     assert [int(v) for v in g["steps_run_p4"]] == [4, 4, 4]
+
+
+def _sd(g, prefix):
+    return {k[len(prefix) + 2:]: t(g[k]) for k in g.files if k.startswith(prefix + "::")}
+
+
+def test_latent_mlps_and_trainers_match_reference(golden):
+    """solpex/latent.py MLPs (forward, gradients) and the three trainers' histories / final weights vs the live reference."""
+    from oracle import latent_ref
+    g = golden("latent_mlp.npz")
+    P_tr, P_va, Z_tr, Z_va = (g[k] for k in ("P_tr", "P_va", "Z_tr", "Z_va"))
+    for name, a, b in (("p2z", P_va, Z_va), ("z2p_ln", Z_va, P_va)):
+        sd = {k: v.requires_grad_(True) for k, v in _sd(g, f"init_{name}").items()}
+        x = t(a).requires_grad_(True)
+        out = latent_ref.mlp_forward(sd, x)
+        loss = latent_ref.smooth_l1(out, t(b))
+        loss.backward()
+        assert max_err(out, g[f"fwd_{name}::out"]) < 2e-6 and abs(float(loss) - float(g[f"fwd_{name}::loss"])) < 1e-6
+        assert max_err(x.grad, g[f"fwd_{name}::dx"]) < 1e-6
+        for k, v in sd.items():
+            assert max_err(v.grad, g[f"fwd_{name}::grad::{k}"]) < 1e-6, k
+    kw = dict(lr=2e-3, epochs=int(g["epochs"]), batch_size=int(g["batch_size"]), wd=1e-4)
+    torch.manual_seed(31)
+    fin, h = latent_ref.train_single(_sd(g, "init_p2z"), P_tr, Z_tr, P_va, Z_va, **kw)
+    assert np.allclose(h["tr"], g["hist_param2z_tr"], rtol=2e-5) and np.allclose(h["va"], g["hist_param2z_va"], rtol=2e-5)
+    for k, v in fin.items():
+        assert max_err(v, g[f"final_param2z::{k}"]) < 2e-5, k
+    torch.manual_seed(32)
+    fin, h = latent_ref.train_single(_sd(g, "init_z2p_ln"), Z_tr, P_tr, Z_va, P_va, **kw)
+    assert np.allclose(h["tr"], g["hist_z2param_ln_tr"], rtol=2e-5) and np.allclose(h["va"], g["hist_z2param_ln_va"], rtol=2e-5)
+    for k, v in fin.items():
+        assert max_err(v, g[f"final_z2param_ln::{k}"]) < 2e-5, k
+    torch.manual_seed(33)
+    fa, fb, h = latent_ref.train_cycle(_sd(g, "init_p2z"), _sd(g, "init_z2p"), Z_tr, P_tr, Z_va, P_va,
+                                       lam_cycle=float(g["lam_cycle"]), **kw)
+    for k in h:
+        assert np.allclose(h[k], g[f"hist_cycle_{k}"], rtol=2e-5), k
+    for k, v in fa.items():
+        assert max_err(v, g[f"final_cycle_p2z::{k}"]) < 2e-5, k
+    for k, v in fb.items():
+        assert max_err(v, g[f"final_cycle_z2p::{k}"]) < 2e-5, k

@@ -126,6 +126,65 @@ def latent_case():
     save("unet_latent.npz", **arrs)
 
 
+def latent_mlp_case():
+    """solpex/latent.py: the two MLPs, one forward + gradient check each, and a few epochs of every trainer."""
+    from solpex import latent as ref_latent
+    rng = np.random.default_rng(5)
+    Pd, zd, hid = 5, 16, (32, 32)
+    Ntr, Nva = 72, 24
+    Wm = rng.normal(size=(Pd, zd)).astype(np.float32) * 0.6
+    P_tr = rng.normal(size=(Ntr, Pd)).astype(np.float32); P_va = rng.normal(size=(Nva, Pd)).astype(np.float32)
+    Z_tr = np.tanh(P_tr @ Wm).astype(np.float32) + 0.05 * rng.normal(size=(Ntr, zd)).astype(np.float32)
+    Z_va = np.tanh(P_va @ Wm).astype(np.float32) + 0.05 * rng.normal(size=(Nva, zd)).astype(np.float32)
+    arrs = dict(P_tr=P_tr, P_va=P_va, Z_tr=Z_tr, Z_va=Z_va, hidden=np.asarray(hid), epochs=3, batch_size=16, lam_cycle=0.1)
+
+    def put(prefix, sd):
+        for k, v in sd.items():
+            arrs[f"{prefix}::{k}"] = v.detach().clone()
+
+    def clone(sd):
+        return {k: v.detach().clone() for k, v in sd.items()}
+    torch.manual_seed(21)
+    p2z = ref_latent.ParamToZ(Pd, zd, hidden=hid)
+    z2p = ref_latent.ZToParam(zd, Pd, hidden=hid)
+    z2p_ln = ref_latent.ZToParam(zd, Pd, hidden=hid, use_layernorm=True)
+    with torch.no_grad():                      # LayerNorm affine away from the identity
+        for m in z2p_ln.net:
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.add_(0.2 * torch.randn_like(m.weight)); m.bias.add_(0.1 * torch.randn_like(m.bias))
+    init = dict(p2z=clone(p2z.state_dict()), z2p=clone(z2p.state_dict()), z2p_ln=clone(z2p_ln.state_dict()))
+    for k, sd in init.items():
+        put(f"init_{k}", sd)
+    # forward + gradients of a SmoothL1 loss (both MLP variants)
+    for name, m, a, b in (("p2z", p2z, P_va, Z_va), ("z2p_ln", z2p_ln, Z_va, P_va)):
+        x = torch.from_numpy(a).clone().requires_grad_(True)
+        out = m(x)
+        loss = torch.nn.SmoothL1Loss(beta=0.05)(out, torch.from_numpy(b))
+        loss.backward()
+        arrs[f"fwd_{name}::out"] = out
+        arrs[f"fwd_{name}::loss"] = loss
+        arrs[f"fwd_{name}::dx"] = x.grad
+        for k, p in m.named_parameters():
+            arrs[f"fwd_{name}::grad::{k}"] = p.grad.clone()
+            p.grad = None
+    kw = dict(device="cpu", lr=2e-3, epochs=3, batch_size=16, wd=1e-4)
+    torch.manual_seed(31)
+    m, h = ref_latent.train_param2z(P_train=P_tr, Z_train=Z_tr, P_val=P_va, Z_val=Z_va, model=p2z, **kw)
+    put("final_param2z", m.state_dict()); arrs["hist_param2z_tr"] = h["tr"]; arrs["hist_param2z_va"] = h["va"]
+    torch.manual_seed(32)
+    m, h = ref_latent.train_z2param(Z_train=Z_tr, P_train=P_tr, Z_val=Z_va, P_val=P_va, model=z2p_ln, **kw)
+    put("final_z2param_ln", m.state_dict()); arrs["hist_z2param_ln_tr"] = h["tr"]; arrs["hist_z2param_ln_va"] = h["va"]
+    p2z2 = ref_latent.ParamToZ(Pd, zd, hidden=hid); p2z2.load_state_dict(init["p2z"])
+    z2p2 = ref_latent.ZToParam(zd, Pd, hidden=hid); z2p2.load_state_dict(init["z2p"])
+    torch.manual_seed(33)
+    a, b, h = ref_latent.train_cycle_consistent(Z_train=Z_tr, P_train=P_tr, Z_val=Z_va, P_val=P_va, p2z_model=p2z2,
+                                                z2p_model=z2p2, lam_cycle=0.1, **kw)
+    put("final_cycle_p2z", a.state_dict()); put("final_cycle_z2p", b.state_dict())
+    for k, v in h.items():
+        arrs[f"hist_cycle_{k}"] = v
+    save("latent_mlp.npz", **arrs)
+
+
 def loss_cases():
     g = torch.Generator().manual_seed(11)
     B, C, H, W = 2, 3, 12, 10
@@ -360,6 +419,7 @@ def main():
     unet_case("unet_cfgA_summary.npz", UNetCfg(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3),
               B=2, H=128, W=64, seed=0, loss_kw=prod, store_weights=False, summary_only=True, empty_last=False)
     latent_case()
+    latent_mlp_case()
     loss_cases()
     norm_cases()
     adamw_case()

@@ -54,6 +54,11 @@ SIGNATURES = {
     "sx_maxpool2_backward_add": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sx_channel_sum": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "sx_global_avg_pool": (_i, [_i, _i, _i, _i, _p, _i, _p, _p]),
+    "sx_gemm_f32": (_i, [_i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _l, _p, _i, _p, _l, _p, _l, _p, _l, _p, _i, _p]),
+    "sx_layernorm_forward": (_i, [_i, _i, _p, _p, _p, _f, _p, _p, _p]),
+    "sx_layernorm_backward": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "sx_smooth_l1": (_i, [_l, _p, _p, _f, _p, _p, _f, _i, _p]),
+    "sx_mul": (_i, [_l, _p, _p, _p, _p]),
     "sx_gather_rows": (_i, [_p, _l, _l, _p, _i, _l, _p, _l, _p]),
     "sx_zero_border": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "sx_loss_workspace_bytes": (_l, [_i] * 6),

@@ -101,47 +101,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int bimg = tt;
     const int ty0 = ty_i * a.TH, tx0 = tx_i * a.TW;
     __syncthreads();
-    // staging with U independent global loads in flight per thread (a dependent load per iteration left a block of one
-    // or two tiles waiting on ~20 serial HBM round trips)
-    constexpr int U = 8;
-    for (int p0 = tid; p0 < a.TP * PPIECES; p0 += 256 * U) {
-      Vec v[U];
-      int dst[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int p = p0 + u * 256;
-        const int m = p / PPIECES, q = p - m * PPIECES;
-        const int py = ty0 + (m >> a.tw_log2), px = tx0 + (m & (a.TW - 1));
-        const int c = a0 + q * EPL;
-        v[u] = Vec{};
-        dst[u] = p < a.TP * PPIECES ? m * PROW + q * 16 : -1;
-        if (dst[u] >= 0 && py < a.H && px < a.W && c < a.Ca)
-          v[u] = *reinterpret_cast<const Vec*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<Vec*>(sP + dst[u]) = v[u];
+    for (int p = tid; p < a.TP * PPIECES; p += 256) {
+      const int m = p / PPIECES, q = p - m * PPIECES;
+      const int py = ty0 + (m >> a.tw_log2), px = tx0 + (m & (a.TW - 1));
+      const int c = a0 + q * EPL;
+      Vec v = {};
+      if (py < a.H && px < a.W && c < a.Ca)
+        v = *reinterpret_cast<const Vec*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
+      *reinterpret_cast<Vec*>(sP + m * PROW + q * 16) = v;
     }
     const int qy0 = ty0 * a.q_scale - a.pad, qx0 = tx0 * a.q_scale - a.pad;
-    const int qtotal = a.LH * a.LW * QPIECES;
-    for (int p0 = tid; p0 < qtotal; p0 += 256 * U) {
-      Vec v[U];
-      int dst[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int p = p0 + u * 256;
-        const int r = p / QPIECES, q = p - r * QPIECES;
-        const int ly = r / a.LW, lx = r - ly * a.LW;
-        const int qy = qy0 + ly, qx = qx0 + lx;
-        const int c = b0 + q * EPL;
-        v[u] = Vec{};
-        dst[u] = p < qtotal ? r * QROW + q * 16 : -1;
-        if (dst[u] >= 0 && qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
-          v[u] = *reinterpret_cast<const Vec*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<Vec*>(sQ + dst[u]) = v[u];
+    for (int p = tid; p < a.LH * a.LW * QPIECES; p += 256) {
+      const int r = p / QPIECES, q = p - r * QPIECES;
+      const int ly = r / a.LW, lx = r - ly * a.LW;
+      const int qy = qy0 + ly, qx = qx0 + lx;
+      const int c = b0 + q * EPL;
+      Vec v = {};
+      if (qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
+        v = *reinterpret_cast<const Vec*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
+      *reinterpret_cast<Vec*>(sQ + r * QROW + q * 16) = v;
     }
     __syncthreads();
 
