@@ -23,6 +23,7 @@ struct ConvArgs {
   // fused variants of the weights-stationary kernel (conv_ws.hip)
   const void* w2;     // packed 1x1 weights: shortcut forward (second output) / shortcut dgrad (extra centre-tap K chunks)
   void* y2; int y2_ld;
+  unsigned long long* stamps;    // diagnostic build (-DSX_WS_DBG=1) only: per-block s_memtime stamps
   float* ch_sum; int ch_sum_n;   // optional: ch_sum[c] += sum over all output pixels of y[..., c], c < ch_sum_n (atomics)
 };
 

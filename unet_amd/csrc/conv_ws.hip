@@ -15,7 +15,13 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifndef SX_WS_DBG
+#define SX_WS_DBG 0        // 1: in-kernel s_memtime stamps (tools/conv_stamps.py); never in the shipped library
+#endif
+
 namespace sx {
+
+static constexpr bool WS_DBG = SX_WS_DBG != 0;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -61,6 +67,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   extern __shared__ __align__(16) char smem[];
   float* sm_stat = reinterpret_cast<float*>(smem + NBUF * BUF);   // [WN][BMC][2]
 
+  const unsigned long long t_entry = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long t_first = 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int n = lane & 15, g = lane >> 4;
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
 #pragma unroll
   for (int k = 0; k < DIST; ++k) issue_stage();
+  const unsigned long long t_setup = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
   const bool do_stats = a.gn_stats != nullptr;
   const bool do_chsum = a.ch_sum != nullptr;       // per-channel output sums (a bias gradient riding on a data gradient)
   int s = 0;
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       wait_vmcnt<(DIST - 1) * NP>();                 // this wave's pieces of stage s have landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
+      if (WS_DBG && s == 0) t_first = __builtin_amdgcn_s_memtime();
       issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
       const char* buf = smem + (s % NBUF) * BUF + frag_off;
       if constexpr (VAR == WS_CENTER) {
@@ -321,7 +331,13 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       atomicAdd(a.ch_sum + cb + tid, t1);
     }
   }
+  const unsigned long long t_loop = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
+  if (WS_DBG && a.stamps && tid == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    o[0] = t_entry; o[1] = t_setup; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
+    o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = (unsigned long long)(t_end - t_begin);
+  }
 }
 
 template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int TWL, int VAR>
@@ -341,6 +357,7 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
     configured = true;
   }
   a.TH = TH; a.TW = TW;
+  if (WS_DBG) a.stamps = getenv("SX_WS_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WS_STAMPS"), nullptr, 0) : nullptr;
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
   const int ntiles = a.B * a.tiles_x * a.tiles_y;

@@ -610,7 +610,9 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
                            at(wpack, p.upb[j]), nullptr, at(ws, prev.dO), p.C[l + 1], p.H[l + 1], p.W[l + 1], 0, nullptr, 0, stream));
   }
   SX_TRY(wq.finish());
-  if (film) SX_TRY(film_run_backward(p, D + 1, 2 * D + 1, params, grads, ws, film_params, flags, st));
+  // SX_BWD_DEFER_FILM: the decoder's FiLM generators are back-propagated by sx_unet_encode_backward together with the
+  // encoder's (one launch pair per step instead of two; each pair is ~45 us of latency-bound work on a few CUs)
+  if (film && !(flags & SX_BWD_DEFER_FILM)) SX_TRY(film_run_backward(p, D + 1, 2 * D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }
 
@@ -644,6 +646,6 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, wq, st));
   }
   SX_TRY(wq.finish());
-  if (film) SX_TRY(film_run_backward(p, 0, D + 1, params, grads, ws, film_params, flags, st));
+  if (film) SX_TRY(film_run_backward(p, 0, (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1, params, grads, ws, film_params, flags, st));
   return SX_OK;
 }

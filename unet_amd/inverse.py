@@ -102,8 +102,8 @@ class _Problem:
 
     def backward_params(self, p):
         s = self.sess
-        s.decode_backward(p, None, L.SX_BWD_ZERO_DPARAMS)        # data gradients only
-        s.encode_backward(p, 0)
+        s.decode_backward(p, None, L.SX_BWD_ZERO_DPARAMS | L.SX_BWD_DEFER_FILM)        # data gradients only
+        s.encode_backward(p, L.SX_BWD_DEFER_FILM)
         return s.view(L.SX_T_FILM_DPARAMS)
 
 

@@ -71,9 +71,11 @@ class TrainEngine:
         self.lr, self.wd, self.clip, self.betas, self.eps = float(lr), float(weight_decay), clip_grad, betas, float(eps)
         self.cfg = model._cfg
         names = model._names
-        # arena order: decoder half first (its bucket is all-reduced while the encoder's backward runs)
-        dec = [names[i] for i in model._dec_idx]
-        enc = [names[i] for i in model._enc_idx]
+        # arena order: decoder half first (its bucket is all-reduced while the encoder's backward runs).  The decoder's
+        # FiLM generators belong to the second bucket: their gradients come out of sx_unet_encode_backward
+        # (SX_BWD_DEFER_FILM: one FiLM backward launch pair per step)
+        dec = [names[i] for i in model._dec_idx if not names[i].startswith("film_dec.")]
+        enc = [names[i] for i in model._dec_idx if names[i].startswith("film_dec.")] + [names[i] for i in model._enc_idx]
         self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + enc)
         self.n_dec = self.slots[enc[0]][0] if enc else self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
@@ -170,7 +172,7 @@ class TrainEngine:
         sess.decode(fp, drop_table)
         lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
         out = self._loss(sess, bufs, y, mask, lg, True, 1.0 / max(int(grad_accum_steps), 1))
-        flags = L.SX_BWD_WEIGHT_GRADS | (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0)
+        flags = L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0)
         sess.decode_backward(fp, drop_table, flags | L.SX_BWD_ZERO_DPARAMS)
         h_dec = None
         closing = step_now and (self.accum + 1 >= max(int(grad_accum_steps), 1))
