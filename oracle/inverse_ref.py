@@ -59,3 +59,35 @@ def inverse_case(sd, cfg, mask_1, y_true_norm_1, p0_1, field_idx, cw_sel, *, ste
         fit = float(weighted_masked_mse(y_pred[:, field_idx], y_sel, mask_1, cw_sel))
         mae = float(masked_mae(y_pred[:, field_idx], y_sel, mask_1))
     return p_var.detach()[0].clone(), fit, mae, losses
+
+
+def inverse_case_lbfgs(sd, cfg, mask_1, y_true_norm_1, p0_1, field_idx, cw_sel, *, steps, reg, clip):
+    """The script's default optimiser path (:336-342 torch.optim.LBFGS(lr 1, max_iter 20, strong Wolfe), closure :359-370,
+    clamp :388-390, final evaluation :413-416) for one case.  Returns (p_final, final fit, per-step last-closure losses,
+    per-step closure counts).  Pinned by tests/golden/inverse_lbfgs.npz."""
+    sd = {k: v.detach() for k, v in sd.items()}
+    y_sel = y_true_norm_1[:, field_idx]
+    p_var = torch.nn.Parameter(p0_1.clone())
+    opt = torch.optim.LBFGS([p_var], lr=1.0, max_iter=20, line_search_fn="strong_wolfe")
+    losses, counts = [], []
+    for _ in range(steps):
+        last, n = [None], [0]
+
+        def closure():
+            opt.zero_grad(set_to_none=True)
+            y_pred = unet_ref.unet_forward(sd, cfg, mask_1, p_var)
+            loss = weighted_masked_mse(y_pred[:, field_idx], y_sel, mask_1, cw_sel) + reg * (p_var ** 2).mean()
+            loss.backward()
+            last[0] = float(loss.item())
+            n[0] += 1
+            return loss
+        opt.step(closure)
+        if clip is not None and clip > 0:
+            with torch.no_grad():
+                p_var.clamp_(-float(clip), float(clip))
+        losses.append(last[0])
+        counts.append(n[0])
+    with torch.no_grad():
+        y_pred = unet_ref.unet_forward(sd, cfg, mask_1, p_var)
+        fit = float(weighted_masked_mse(y_pred[:, field_idx], y_sel, mask_1, cw_sel))
+    return p_var.detach()[0].clone(), fit, losses, counts

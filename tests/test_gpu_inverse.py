@@ -101,3 +101,23 @@ def test_config4_shape_properties_bf16():
     assert float(better) > 0.8
     assert float(full["fit"][5]) == 0.0 and float(full["p_scaled"][5].abs().max()) < 1e-2
     assert [int(v) for v in full["steps_run"].cpu()] == [6] * N
+
+
+def test_lbfgs_path_matches_reference_trajectories(golden):
+    """optimizer="lbfgs" (the reference script's default): host L-BFGS + strong Wolfe around the device closure.  fp32 tier;
+    the line search amplifies rounding, so the recovered parameters get 2e-2 and the losses 1e-3."""
+    from unet_amd.inverse import batched_inverse
+    g, gl = golden("inverse_case.npz"), golden("inverse_lbfgs.npz")
+    model = _model(g)
+    N = int(gl["n_cases"])
+    mask, yt, p0 = (t(g[k])[:N].cuda() for k in ("mask", "y_true_norm", "p0"))
+    res = batched_inverse(model, mask, yt, p0, field_idx=[int(i) for i in g["field_idx"]], channel_weights=t(g["cw_sel"]),
+                          steps=int(gl["steps"]), optimizer="lbfgs", reg=float(g["reg"]), clip_scaled=float(g["clip"]),
+                          early_stop_patience=0, dtype=torch.float32, return_history=True)
+    h = res["loss_history"].cpu().numpy()
+    assert np.allclose(h, gl["hist"], rtol=1e-3), (h, gl["hist"])
+    assert np.allclose(res["fit"].cpu().numpy(), gl["fit_final"], rtol=1e-3)
+    assert np.abs(res["p_scaled"].cpu().numpy() - gl["p_final"]).max() < 2e-2
+    assert res["steps_run"].tolist() == [int(gl["steps"])] * N
+    with pytest.raises(ValueError):
+        batched_inverse(model, mask, yt, p0, optimizer="sgd")

@@ -184,3 +184,21 @@ def test_latent_mlps_and_trainers_match_reference(golden):
         assert max_err(v, g[f"final_cycle_p2z::{k}"]) < 2e-5, k
     for k, v in fb.items():
         assert max_err(v, g[f"final_cycle_z2p::{k}"]) < 2e-5, k
+
+
+def test_inverse_lbfgs_matches_reference(golden):
+    """The script's default L-BFGS path (strong Wolfe) against the live-reference trajectories: same closure counts,
+    same last-closure losses, same recovered parameters."""
+    from oracle import inverse_ref
+    g, gl = golden("inverse_case.npz"), golden("inverse_lbfgs.npz")
+    cfg = cfg_from_golden(g)
+    sd = sd_from_golden(g, cfg)
+    mask, yt, p0 = t(g["mask"]), t(g["y_true_norm"]), t(g["p0"])
+    fidx = [int(i) for i in g["field_idx"]]
+    for n in range(int(gl["n_cases"])):
+        p, fit, losses, counts = inverse_ref.inverse_case_lbfgs(sd, cfg, mask[n:n + 1], yt[n:n + 1], p0[n:n + 1], fidx, t(g["cw_sel"]),
+                                                                steps=int(gl["steps"]), reg=float(g["reg"]), clip=float(g["clip"]))
+        assert counts == [int(v) for v in gl["n_evals"][:, n]]
+        assert np.allclose(losses, gl["hist"][:, n], rtol=1e-5)
+        assert abs(fit - float(gl["fit_final"][n])) < 1e-5 * abs(fit)
+        assert max_err(p, gl["p_final"][n]) < 1e-3

@@ -406,6 +406,54 @@ def inverse_case():
     save("inverse_case.npz", **arrs)
 
 
+def inverse_lbfgs_case():
+    """The script's DEFAULT optimiser path (:336-342,356-373: torch.optim.LBFGS, lr 1, max_iter 20, strong Wolfe) on the
+    live reference, same imported script functions and set-up as inverse_case; the fixture of inverse_case.npz supplies
+    the weights, masks, targets and starting points (this file only adds the L-BFGS trajectories)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_inverse_script",
+                                                  "/root/reference/scripts/eval_inverse_cycle_conditional_unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g0 = np.load(os.path.join(OUT, "inverse_case.npz"))
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = {k[3:]: torch.from_numpy(g0[k]).clone() for k in g0.files if k.startswith("w::")}
+    model = ref_model(cfg, sd).eval()
+    mask, y_true_norm, p0 = (torch.from_numpy(g0[k]) for k in ("mask", "y_true_norm", "p0"))
+    field_idx = [int(i) for i in g0["field_idx"]]
+    cw_sel = torch.from_numpy(g0["cw_sel"])
+    N, steps, reg, clip = 2, 4, float(g0["reg"]), float(g0["clip"])
+    hist = np.zeros((steps, N)); hfit = np.zeros((steps, N)); nev = np.zeros((steps, N))
+    p_fin, fit_fin = [], []
+    for n in range(N):
+        m_t = mask[n:n + 1]
+        y_sel = y_true_norm[n:n + 1][:, field_idx]
+        p_var = torch.nn.Parameter(p0[n:n + 1].clone())
+        opt = torch.optim.LBFGS([p_var], lr=1.0, max_iter=20, line_search_fn="strong_wolfe")
+        for step in range(steps):
+            _loss_val, _fit_val, _n = [None], [None], [0]
+
+            def closure():
+                opt.zero_grad(set_to_none=True)
+                x = mod.build_x_from_mask(m_t)
+                y_pred_norm = model(x, params=p_var)
+                loss_fit = mod.weighted_masked_mse(y_pred_norm[:, field_idx], y_sel, m_t, cw_sel)
+                loss = loss_fit + reg * (p_var ** 2).mean()
+                loss.backward()
+                _loss_val[0] = float(loss.item()); _fit_val[0] = float(loss_fit.item()); _n[0] += 1
+                return loss
+            opt.step(closure)
+            with torch.no_grad():
+                p_var.clamp_(-clip, clip)
+            hist[step, n], hfit[step, n], nev[step, n] = _loss_val[0], _fit_val[0], _n[0]
+        with torch.no_grad():
+            y_pred = model(mod.build_x_from_mask(m_t), params=p_var)
+            fit_fin.append(float(mod.weighted_masked_mse(y_pred[:, field_idx], y_sel, m_t, cw_sel)))
+        p_fin.append(p_var.detach().numpy()[0].copy())
+    save("inverse_lbfgs.npz", n_cases=N, steps=steps, hist=hist, hist_fit=hfit, n_evals=nev, p_final=np.stack(p_fin),
+         fit_final=np.asarray(fit_fin))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     prod = dict(lam_grad=0.1, lam_w=0.5, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
@@ -425,6 +473,7 @@ def main():
     adamw_case()
     train_case()
     inverse_case()
+    inverse_lbfgs_case()
 
 
 if __name__ == "__main__":

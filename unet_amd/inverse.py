@@ -7,7 +7,9 @@ per SAMPLE: loss denominators, the L2 regulariser, Adam state, clamp and early s
 network is computed (`SX_BWD_WEIGHT_GRADS` off): the reference's `loss.backward()` also fills every weight gradient and
 throws it away.
 
-`optimizer="lbfgs"` (the reference script's default) is not implemented on the device: NotImplementedError.
+`optimizer="lbfgs"` (the reference script's default, :336-342) keeps the reference's structure: torch.optim.LBFGS is host
+control logic over five numbers per case (two-loop recursion, strong-Wolfe line search), so cases run one after the other
+and only the closure -- network forward, per-sample fit, data-gradient backward -- runs on the device (B = 1 session).
 """
 from __future__ import annotations
 
@@ -117,8 +119,8 @@ def batched_inverse(model, mask, y_true_norm, p0, *, field_idx=None, channel_wei
     normalised space;  p0 (N,P) initial scaled parameters.  Returns dict: p_scaled (N,P), fit (N,) final
     weighted_masked_mse (:413-416), cycle_mae_norm (N,) (:439), steps_run (N,), and loss_history (steps,N) if requested
     (NaN where a case had already stopped)."""
-    if optimizer != "adam":
-        raise NotImplementedError("unet_amd.inverse: only the reference's Adam path is implemented on the device (lbfgs is not)")
+    if optimizer not in ("adam", "lbfgs"):
+        raise ValueError(f"unet_amd.inverse: unknown optimizer {optimizer!r} (adam | lbfgs)")
     if model.P <= 0:
         raise ValueError("batched_inverse needs a FiLM-conditioned model (P > 0)")
     if not p0.is_cuda:
@@ -139,6 +141,9 @@ def batched_inverse(model, mask, y_true_norm, p0, *, field_idx=None, channel_wei
         hist = torch.full((steps, N), float("nan"), dtype=torch.float32, device=dev) if return_history else None
         lib = L.lib()
         prob = None
+        if optimizer == "lbfgs":
+            return _lbfgs_cases(model, mask3, tgt, p_all, w, sel, sx_dtype, steps, reg, clip_scaled, early_stop_patience,
+                                early_stop_tol, fit_all, mae_all, steps_all, hist)
         for lo in range(0, N, batch):
             hi = min(N, lo + batch)
             B = hi - lo
@@ -173,6 +178,54 @@ def batched_inverse(model, mask, y_true_norm, p0, *, field_idx=None, channel_wei
         return out
     finally:
         model.train(was_training)
+
+
+def _lbfgs_cases(model, mask3, tgt, p_all, w, sel, sx_dtype, steps, reg, clip, patience, tol, fit_all, mae_all, steps_all, hist):
+    """Reference loop :336-416 with use_lbfgs: per case, torch.optim.LBFGS(lr 1, max_iter 20, strong Wolfe) around a device
+    closure.  As in the reference, the value logged / early-stopped on is the LAST closure evaluation of each step."""
+    N, H, W = mask3.shape
+    P = model.P
+    prob = _Problem(model, 1, H, W, sx_dtype)
+    for n in range(N):
+        x, t_, m_ = mask3[n:n + 1].unsqueeze(1), tgt[n:n + 1], mask3[n:n + 1]
+        p_var = torch.nn.Parameter(p_all[n:n + 1].clone())
+        opt = torch.optim.LBFGS([p_var], lr=1.0, max_iter=20, line_search_fn="strong_wolfe")
+        last = [0.0]
+
+        def closure():
+            p = p_var.data
+            prob.forward_fit(x, p, t_, m_, w, sel, True)
+            g = prob.backward_params(p)
+            # loss = fit + reg * mean(p^2)  (:364-366); its gradient in p
+            p_var.grad = g + (2.0 * reg / P) * p
+            loss = prob.fit[0] + reg * (p * p).mean()
+            last[0] = float(loss)
+            return loss
+        best, wait, ran = float("inf"), 0, 0
+        for step in range(steps):
+            opt.step(closure)
+            if clip is not None and clip > 0:
+                p_var.data.clamp_(-float(clip), float(clip))
+            ran += 1
+            if hist is not None:
+                hist[step, n] = last[0]
+            if patience > 0:
+                rel = (best - last[0]) / max(abs(best), 1e-12)       # NaN while best is inf, as in the reference
+                if rel > tol:
+                    best, wait = last[0], 0
+                else:
+                    wait += 1
+                    if wait >= patience:
+                        break
+        p_all[n:n + 1] = p_var.data
+        prob.forward_fit(x, p_all[n:n + 1], t_, m_, w, sel, False)
+        fit_all[n:n + 1] = prob.fit
+        mae_all[n:n + 1] = prob.mae
+        steps_all[n] = ran
+    out = {"p_scaled": p_all, "fit": fit_all, "cycle_mae_norm": mae_all, "steps_run": steps_all}
+    if hist is not None:
+        out["loss_history"] = hist
+    return out
 
 
 def inverse_with_restarts(model, mask, y_true_norm, p0_restarts, **kw):
