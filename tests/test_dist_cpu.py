@@ -91,3 +91,51 @@ def test_dp2_equals_unsplit_batch():
         halves.append(float(loss_ref.masked_weighted_loss(pr, bt["y"][sl], bt["mask"][sl], w=wmap, lam_grad=0.0, lam_w=0.5,
                                                           base="mse", channel_weights=cw)))
     assert abs(0.5 * sum(halves) - float(full)) > 1e-4 * abs(float(full))
+
+
+def _sweep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from unet_amd import dist as D
+    from unet_amd import sweep
+    D.init_from_env(backend="gloo")
+    seen = []
+
+    def run(trial):
+        # inside a trial the process is a single-rank job: nothing would all-reduce
+        assert D.world_size() == 1 and D.rank() == 0 and not D.is_active()
+        if trial["tag"] == "bad":
+            raise RuntimeError("boom")
+        seen.append(trial["tag"])
+        return {"tag": trial["tag"], "val": trial["x"] ** 2, "rank": rank}
+    trials = [{"tag": f"t{i}", "x": i} for i in range(5)] + [{"tag": "bad", "x": 0}]
+    res = sweep.run_trials(trials, run, costs=[5, 1, 1, 1, 1, 1])
+    assert D.world_size() == world and D.is_active()          # local mode ended
+    q.put((rank, res, seen))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sweep_trials_are_partitioned_and_gathered():
+    sys.path.insert(0, ROOT)
+    from unet_amd import sweep
+    assert sweep.assign(5, 2) == [[0, 2, 4], [1, 3]]
+    assert sweep.assign(4, 2, costs=[10, 1, 1, 1]) == [[0], [1, 2, 3]]
+    with pytest.raises(ValueError):
+        sweep.assign(3, 2, costs=[1.0])
+    assert sweep.run_trials([1, 2, 3], lambda v: v * 10) == [10, 20, 30]        # single process
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(2)], key=lambda v: v[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, res0, seen0), (r1, res1, seen1) = out
+    assert res0 == res1                                                          # every rank holds the full table
+    assert [r.get("val") for r in res0[:5]] == [0, 1, 4, 9, 16] and res0[5] == {"error": "boom"}
+    assert sorted(seen0 + seen1) == [f"t{i}" for i in range(5)] and set(seen0).isdisjoint(seen1)
+    assert seen0 == ["t0"]                                                       # the costly trial alone on rank 0 (LPT)

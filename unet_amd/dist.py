@@ -11,21 +11,41 @@ With identical masks on every sample this reduces to ordinary gradient averaging
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import torch
 import torch.distributed as dist
 
 
+_LOCAL = 0          # depth of local_mode(): inside it this process behaves as a single-rank job
+
+
+@contextlib.contextmanager
+def local_mode():
+    """Run the enclosed code as if there were one rank: train_unet / TrainEngine / batched_inverse then neither split nor
+    all-reduce anything.  For trial-level parallelism (unet_amd.sweep), where every rank trains its OWN model."""
+    global _LOCAL
+    _LOCAL += 1
+    try:
+        yield
+    finally:
+        _LOCAL -= 1
+
+
+def _group_ready():
+    return dist.is_available() and dist.is_initialized()
+
+
 def is_active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return not _LOCAL and _group_ready() and dist.get_world_size() > 1
 
 
 def world_size():
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return dist.get_world_size() if (_group_ready() and not _LOCAL) else 1
 
 
 def rank():
-    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return dist.get_rank() if (_group_ready() and not _LOCAL) else 0
 
 
 def init_from_env(backend=None):
