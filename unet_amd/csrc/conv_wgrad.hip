@@ -343,11 +343,11 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
   SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));
   if (mode == SX_CONVT_FWD) SX_REQUIRE(Hq >= 2 * H && Wq >= 2 * W, "sx_conv_wgrad: convT Q dims");
   else SX_REQUIRE(Hq == H && Wq == W, "sx_conv_wgrad: Q dims");
-  if (dtype == SX_BF16 && (int64_t)H * W * std::max(p_ld, q_ld) * 2 < ((int64_t)1 << 30)) {
+  if (dtype == SX_BF16 && (int64_t)Hq * Wq * std::max(p_ld, q_ld) * 2 < ((int64_t)1 << 30)) {
     const int64_t need = wgrad_ws_slab_bytes(mode, B, H, W, Ca, Cb);
     if (need > 0) {
       SX_REQUIRE(need <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %lld)", (long long)slab_bytes, (long long)need);
-      const int rc = wgrad_ws_try(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, (float*)slab, desc, st);
+      const int rc = wgrad_ws_try(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, (float*)slab, desc, st);
       if (rc <= 0) return rc;
     }
   }

@@ -25,7 +25,7 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
 
 // Persistent bf16 tier.  slab bytes it needs (0 = shape not covered) / launch (0 = launched, 1 = not covered, <0 error).
 int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb);
-int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld,
+int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
                  float* slab, WgReduceDesc* desc, hipStream_t st);
 
 }  // namespace sx

@@ -1,6 +1,8 @@
 // Persistent split-K weight-gradient kernel, bf16, gfx950: the fast tier of sx_conv_wgrad for 3x3 / 1x1 convolutions.
 //
 //     dW[tap][a][b] = sum over pixels p of  P[p][a] * Q[p + tap - pad][b]        (P = dY, Q = layer input)
+//     ConvTranspose2d(2,2) (TAPS = 4): P = layer input (a = ci), Q = dY, Q pixel = 2p + tap: the LDS-DMA de-interleaves
+//     the four parity classes of the dY tile into four sub-images with P's pixel order, so a tap is a plain 1x1 product.
 //
 // The reduction dimension is the pixel index (up to 524k per layer at batch 64) and the result is tiny
 // (taps x Ca x Cb), so a block keeps ALL its accumulators in registers while it walks a contiguous range of
@@ -24,6 +26,7 @@ namespace sx {
 struct WgWsArgs {
   const bf16* P; const bf16* Q; float* slab;
   int B, H, W, p_ld, q_ld;
+  int Hq, Wq;                   // Q image dims (= H, W except for the transposed conv: >= 2H, 2W)
   int Ca, Cb, CaPad, CbPad;
   int a_tiles, b_tiles, tg_count, R, S;
   int tiles_x, tiles_y, ntiles, tiles_per_split;
@@ -94,18 +97,21 @@ static constexpr bool DBG = false;  // SX_WG_DBG ablation switches (bit 0: no MF
 template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF>
 __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr bool CT = TAPS == 4;                       // transposed conv: four parity sub-images of Q, no halo
+  static_assert(!CT || (TGH == 1 && TGW == 1), "transposed conv: taps are sub-images, not shifts");
   constexpr int TW = 1 << TWL, TH = 128 / TW, YS = 32 / TW;
   constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
   constexpr int PB = MI * 32, QB = NBF * 32;
   constexpr int PP = PB / 16, QP = QB / 16;
   constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
   constexpr int NPP = (128 * PP) / 256;
-  constexpr int QSLOTS = LH * QPITCH * QP;
+  constexpr int QSUB = LH * QPITCH * QB;                // bytes of one Q (sub-)image
+  constexpr int QSLOTS = (CT ? 4 : 1) * LH * QPITCH * QP;
   constexpr int NPQ = (QSLOTS + 255) / 256;
   constexpr int NPT = NPP + NPQ;
   constexpr int BUF = NPT * 4096;
   constexpr int DIST = NBUF - 1;
-  constexpr int NIT = TGH * TGW * NBF, ITEMS = (NIT + 3) / 4;
+  constexpr int NIT = (CT ? 4 : TGH * TGW) * NBF, ITEMS = (NIT + 3) / 4;
   static_assert(NPP >= 1, "P tile smaller than one DMA round");
   extern __shared__ __align__(16) char smem[];
   const unsigned long long t_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   const int nst = t_end - t_begin;
 
   // ---- DMA setup: slot e = tid + q*256 of the P / Q image -> (pixel, piece) it holds -> global offset
-  const int prow_bytes = a.W * a.p_ld * 2, qrow_bytes = a.W * a.q_ld * 2;
-  const int pimg_bytes = a.H * prow_bytes, qimg_bytes = a.H * qrow_bytes;
+  const int prow_bytes = a.W * a.p_ld * 2, qrow_bytes = a.Wq * a.q_ld * 2;
+  const int pimg_bytes = a.H * prow_bytes, qimg_bytes = a.Hq * qrow_bytes;
   int p_rel[NPP], p_x[NPP], q_rel[NPQ], q_x[NPQ];
 #pragma unroll
   for (int q = 0; q < NPP; ++q) {
@@ -151,13 +157,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
 #pragma unroll
   for (int q = 0; q < NPQ; ++q) {
     const int e = tid + q * 256;
-    const int ps = e / QP, cs = e % QP;
+    const int sub = CT ? e / (LH * QPITCH * QP) : 0;          // parity class = tap (ty, tx) of the transposed conv
+    const int es = e - sub * (LH * QPITCH * QP);
+    const int ps = es / QP, cs = es % QP;
     const int y = ps / QPITCH, xs = ps - y * QPITCH;
     const int o = wg_tile_off<QB, TWL>(y, xs, QPITCH, cs) >> 4;
     const int x = (o / QP) - y * QPITCH, c = o % QP;
-    const bool ok = y < LH && x < LW && b0 + c * 8 < a.Cb;
-    q_x[q] = ok ? x + ox - PAD : -100000;
-    q_rel[q] = (y + oy - PAD) * qrow_bytes + (x + ox - PAD) * a.q_ld * 2 + (b0 + c * 8) * 2;
+    const bool ok = sub < 4 && y < LH && x < LW && b0 + c * 8 < a.Cb;
+    if constexpr (CT) {
+      q_x[q] = ok ? x : -100000;                               // bounds are checked on the P (low-resolution) grid
+      q_rel[q] = (2 * y + (sub >> 1)) * qrow_bytes + (2 * x + (sub & 1)) * a.q_ld * 2 + (b0 + c * 8) * 2;
+    } else {
+      q_x[q] = ok ? x + ox - PAD : -100000;
+      q_rel[q] = (y + oy - PAD) * qrow_bytes + (x + ox - PAD) * a.q_ld * 2 + (b0 + c * 8) * 2;
+    }
   }
 
   // A stage's NPT pieces are issued one by one (stage_begin, issue_piece<q> ..., stage_end) so the main loop can
@@ -173,11 +186,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
     ibuf = smem + (is % NBUF) * BUF + wid * 1024;
     const bool live = is < nst && !(DBG && (a.dbg & 2));
     rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (int64_t)ip.b * a.H * a.W * a.p_ld), 0, live ? pimg_bytes : 0, 0x00020000);
-    rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Q + (int64_t)ip.b * a.H * a.W * a.q_ld), 0, live ? qimg_bytes : 0, 0x00020000);
+    rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Q + (int64_t)ip.b * a.Hq * a.Wq * a.q_ld), 0, live ? qimg_bytes : 0, 0x00020000);
     ix0 = ip.tx * TW;
     const int y0 = ip.ty * TH;
     ipoff = y0 * prow_bytes + ix0 * a.p_ld * 2;
-    iqoff = y0 * qrow_bytes + ix0 * a.q_ld * 2;
+    iqoff = (CT ? 2 : 1) * (y0 * qrow_bytes + ix0 * a.q_ld * 2);
   };
   auto issue_piece = [&](auto QI) {
     constexpr int q = decltype(QI)::value;
@@ -216,12 +229,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
     it_valid[t] = it < NIT;
     const int itc = it_valid[t] ? it : 0;
     const int tl = itc / NBF, bf = itc - tl * NBF;
-    const int dy = tl / TGW, dx = tl - dy * TGW;
-    it_tap[t] = TAPS == 9 ? (oy + dy) * 3 + (ox + dx) : 0;
+    const int dy = CT ? 0 : tl / TGW, dx = CT ? 0 : tl - dy * TGW;
+    it_tap[t] = TAPS == 9 ? (oy + dy) * 3 + (ox + dx) : (CT ? tl : 0);
     it_bf[t] = bf;
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd)
-      offQ[t][rd] = NPP * 4096 + wg_tile_off<QB, TWL>(yl + dy, xl + dx + 4 * rd, QPITCH, 2 * bf + hh) + lo;
+      offQ[t][rd] = NPP * 4096 + (CT ? tl * QSUB : 0) + wg_tile_off<QB, TWL>(yl + dy, xl + dx + 4 * rd, QPITCH, 2 * bf + hh) + lo;
   }
 
   f32x4 acc[ITEMS][MI];
@@ -321,15 +334,20 @@ struct WgWsPlan {
 static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
   WgWsPlan p;
   memset(&p, 0, sizeof(p));
-  if (mode != SX_CONV3 && mode != SX_CONV1) return p;
+  if (mode != SX_CONV3 && mode != SX_CONV1 && mode != SX_CONVT_FWD) return p;
   if (W < 8 || Ca % 8 || Cb % 8) return p;
+  const bool ct = mode == SX_CONVT_FWD;
   if ((int64_t)H * W * std::max(Ca, Cb) * 2 >= ((int64_t)1 << 30)) return p;   // 32-bit offsets inside one image
-  p.taps = mode == SX_CONV3 ? 9 : 1;
+  p.taps = mode == SX_CONV3 ? 9 : (ct ? 4 : 1);
   p.CaPad = round_up(Ca, 16); p.CbPad = round_up(Cb, 16);
   p.MI = p.CaPad >= 64 ? 4 : p.CaPad / 16;      // 1, 2, (3 -> 4), 4
   if (p.MI == 3) p.MI = 4;
   p.NBF = p.CbPad >= 64 ? 4 : p.CbPad / 16;
   if (p.NBF == 3) p.NBF = 4;
+  if (ct) {                                      // four Q sub-images per stage: 32 b channels keep three stages in LDS
+    if (p.CaPad < 64 || p.CbPad < 32) { return p; }
+    p.MI = 4; p.NBF = 2;
+  }
   p.a_tiles = cdiv(p.CaPad, p.MI * 16);
   p.b_tiles = cdiv(p.CbPad, p.NBF * 16);
   p.TWL = W >= 16 ? 4 : 3;
@@ -349,7 +367,7 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
     const int R = p.a_tiles * p.b_tiles * tgc;
     // at least MIN_TILES tiles per block: slab traffic (S slabs written, then read by the reduction) is what small-K
     // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
-    const int min_tiles = getenv("SX_WG_MIN_TILES") ? atoi(getenv("SX_WG_MIN_TILES")) : 8;
+    const int min_tiles = getenv("SX_WG_MIN_TILES") ? atoi(getenv("SX_WG_MIN_TILES")) : (ct ? 4 : 8);
     int S = std::max(1, std::min(std::max(1, p.ntiles / min_tiles), 256 / R));
     const int tps = cdiv(p.ntiles, S);
     S = cdiv(p.ntiles, tps);
@@ -370,7 +388,7 @@ static int launch_wgws(const WgWsArgs& a, hipStream_t st) {
   constexpr int TW = 1 << TWL, TH = 128 / TW;
   constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
   constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
-  constexpr int NPT = (128 * MI * 2) / 256 + (LH * QPITCH * NBF * 2 + 255) / 256;
+  constexpr int NPT = (128 * MI * 2) / 256 + ((TAPS == 4 ? 4 : 1) * LH * QPITCH * NBF * 2 + 255) / 256;
   constexpr int NBUF = NPT * 4096 * 4 <= 160 * 1024 ? 4 : 3;
   const size_t smem = (size_t)NBUF * NPT * 4096;
   auto kern = wgrad_ws_kernel<TAPS, TGH, TGW, MI, NBF, TWL, NBUF>;
@@ -403,6 +421,7 @@ static int wgws_pick_frag(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) 
 
 template <int TWL>
 static int wgws_pick_taps(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) {
+  if (p.taps == 4) return launch_wgws<4, 1, 1, 4, 2, TWL>(a, st);
   if (p.taps == 1) return wgws_pick_frag<1, 1, 1, TWL>(p, a, st);
   if (p.tgk == 0) return wgws_pick_frag<9, 3, 3, TWL>(p, a, st);
   if (p.tgk == 1) return wgws_pick_frag<9, 1, 3, TWL>(p, a, st);
@@ -414,14 +433,14 @@ int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
   return p.ok ? p.slab_bytes : 0;
 }
 
-int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld,
+int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
                  float* slab, WgReduceDesc* desc, hipStream_t st) {
   const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
   if (!p.ok) return 1;
   WgWsArgs a;
   memset(&a, 0, sizeof(a));
   a.P = (const bf16*)P; a.Q = (const bf16*)Q; a.slab = slab;
-  a.B = B; a.H = H; a.W = W; a.p_ld = p_ld; a.q_ld = q_ld;
+  a.B = B; a.H = H; a.W = W; a.p_ld = p_ld; a.q_ld = q_ld; a.Hq = Hq; a.Wq = Wq;
   a.Ca = Ca; a.Cb = Cb; a.CaPad = p.CaPad; a.CbPad = p.CbPad;
   a.a_tiles = p.a_tiles; a.b_tiles = p.b_tiles; a.tg_count = p.tg_count; a.R = p.R; a.S = p.S;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
