@@ -112,6 +112,50 @@ __global__ __launch_bounds__(256) void den_kernel(const float* __restrict__ m, c
   }
 }
 
+// Single-scale fast path of phase 1 (multiscale = 0, the production setting): ONE block per sample forms
+// {sum m, sum m*w, sum m_g} of its sample and the pooled + thresholded gradient-term mask, a second one-block kernel adds the
+// per-sample partials in a fixed order into den (deterministic; replaces a memset, two atomic reductions and a pooling launch).
+__global__ __launch_bounds__(256) void prepare1_kernel(const float* __restrict__ m, const float* __restrict__ w, int H, int W, int k,
+                                                       int want_mg, float* __restrict__ mg, float* __restrict__ part) {
+  const int b = blockIdx.x, hw = H * W;
+  const float* mb = m + (int64_t)b * hw;
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+    const float mm = mb[i];
+    v[0] += mm;
+    if (w) v[1] += mm * w[i];
+  }
+  if (want_mg) {
+    if (k > 1) {
+      const int gh = H / k, gw = W / k;
+      const float inv = 1.0f / (float)(k * k);
+      for (int i = threadIdx.x; i < gh * gw; i += blockDim.x) {
+        const int y = i / gw, x = i - y * gw;
+        const float* src = mb + (int64_t)y * k * W + x * k;
+        float sm = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+          for (int dx = 0; dx < k; ++dx) sm += src[dy * W + dx];
+        const float t = sm * inv > 0.5f ? 1.f : 0.f;
+        mg[(int64_t)b * gh * gw + i] = t;
+        v[2] += t;
+      }
+    } else {
+      v[2] = v[0];          // grad_ds = 1: the gradient term uses the mask itself (no threshold)
+    }
+  }
+  __shared__ float red[12];
+  block_sum<3>(v, red);
+  if (threadIdx.x == 0) { part[b * 4 + 0] = v[0]; part[b * 4 + 1] = v[1]; part[b * 4 + 2] = v[2]; }
+}
+
+__global__ void den_reduce_kernel(const float* __restrict__ part, int B, float* __restrict__ den) {
+  const int t = threadIdx.x;
+  if (t >= 9) return;
+  float s = 0.f;
+  if (t < 3) for (int b = 0; b < B; ++b) s += part[b * 4 + t];
+  den[t] = s;
+}
+
 struct BaseArgs {
   const float* p; const float* t; const float* m; const float* w; const float* cw;
   float* g;           // planar gradient at this scale (written, not accumulated)
@@ -303,6 +347,7 @@ struct LossLayout {
   int64_t P[3], T[3], M[3], Wm[3], G[3];     // planar copies per scale (P[0] = unpacked pred; T[0] = caller's target)
   int64_t PG[3], TG[3], MG[3], UX[3], UY[3]; // grad-term buffers per scale
   int64_t NUM;                // 12 floats
+  int64_t PART;               // [B][4] per-sample denominators (single-scale phase 1)
   int64_t total;
 };
 
@@ -313,6 +358,7 @@ static LossLayout loss_layout(int B, int C, int H, int W, int multiscale, int gr
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
   L.NUM = take(NSLOT * SLOT_STRIDE);
+  L.PART = take((int64_t)B * 4);
   int gd = grad_ds < 1 ? 1 : grad_ds;
   for (int s = 0; s < L.ns; ++s) {
     L.h[s] = s == 0 ? H : L.h[s - 1] / 2;
@@ -356,6 +402,14 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
   hipStream_t st = (hipStream_t)stream;
   LossLayout L = loss_layout(B, C, H, W, multiscale, grad_ds);
   float* ws = (float*)workspace;
+  if (L.ns == 1) {
+    const bool want_mg = lam_grad != 0.f;
+    if (want_mg && (L.gh[0] < 1 || L.gw[0] < 1)) { set_error("sx_loss_prepare: grid too small for grad_ds"); return SX_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(prepare1_kernel, dim3(B), dim3(256), 0, st, mask, w, H, W, L.gds[0], want_mg ? 1 : 0, ws + L.MG[0], ws + L.PART);
+    hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(64), 0, st, ws + L.PART, B, den);
+    SX_LAUNCH_CHECK("loss_prepare");
+    return SX_OK;
+  }
   hipError_t e = hipMemsetAsync(den, 0, 9 * sizeof(float), st);
   if (e != hipSuccess) return hip_fail(e, "memset(den)");
   for (int s = 0; s < L.ns; ++s) {
