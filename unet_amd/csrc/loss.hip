@@ -116,11 +116,12 @@ __global__ __launch_bounds__(256) void den_kernel(const float* __restrict__ m, c
 // {sum m, sum m*w, sum m_g} of its sample and the pooled + thresholded gradient-term mask, a second one-block kernel adds the
 // per-sample partials in a fixed order into den (deterministic; replaces a memset, two atomic reductions and a pooling launch).
 __global__ __launch_bounds__(256) void prepare1_kernel(const float* __restrict__ m, const float* __restrict__ w, int H, int W, int k,
-                                                       int want_mg, float* __restrict__ mg, float* __restrict__ part) {
-  const int b = blockIdx.x, hw = H * W;
-  const float* mb = m + (int64_t)b * hw;
+                                                       int want_mg, float* __restrict__ mg, float* __restrict__ part, int rows_per) {
+  // grid = (row chunks, samples); rows_per is a multiple of k, so pooling windows never straddle two blocks
+  const int b = blockIdx.y, y0 = blockIdx.x * rows_per, y1 = min(H, y0 + rows_per);
+  const float* mb = m + (int64_t)b * H * W;
   float v[3] = {0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+  for (int i = y0 * W + threadIdx.x; i < y1 * W; i += blockDim.x) {
     const float mm = mb[i];
     v[0] += mm;
     if (w) v[1] += mm * w[i];
@@ -128,8 +129,9 @@ __global__ __launch_bounds__(256) void prepare1_kernel(const float* __restrict__
   if (want_mg) {
     if (k > 1) {
       const int gh = H / k, gw = W / k;
+      const int g0 = y0 / k, g1 = min(gh, (y1 + k - 1) / k);
       const float inv = 1.0f / (float)(k * k);
-      for (int i = threadIdx.x; i < gh * gw; i += blockDim.x) {
+      for (int i = g0 * gw + threadIdx.x; i < g1 * gw; i += blockDim.x) {
         const int y = i / gw, x = i - y * gw;
         const float* src = mb + (int64_t)y * k * W + x * k;
         float sm = 0.f;
@@ -145,15 +147,20 @@ __global__ __launch_bounds__(256) void prepare1_kernel(const float* __restrict__
   }
   __shared__ float red[12];
   block_sum<3>(v, red);
-  if (threadIdx.x == 0) { part[b * 4 + 0] = v[0]; part[b * 4 + 1] = v[1]; part[b * 4 + 2] = v[2]; }
+  if (threadIdx.x == 0) {
+    float* o = part + ((int64_t)b * gridDim.x + blockIdx.x) * 4;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+  }
 }
 
-__global__ void den_reduce_kernel(const float* __restrict__ part, int B, float* __restrict__ den) {
-  const int t = threadIdx.x;
-  if (t >= 9) return;
-  float s = 0.f;
-  if (t < 3) for (int b = 0; b < B; ++b) s += part[b * 4 + t];
-  den[t] = s;
+// den[0..2] = sums of the n partial triples (fixed order: thread t adds entries t, t + 256, ...; then a tree); den[3..8] = 0
+__global__ __launch_bounds__(256) void den_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ den) {
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { v[0] += part[i * 4]; v[1] += part[i * 4 + 1]; v[2] += part[i * 4 + 2]; }
+  __shared__ float red[12];
+  block_sum<3>(v, red);
+  if (threadIdx.x == 0) { den[0] = v[0]; den[1] = v[1]; den[2] = v[2]; }
+  if (threadIdx.x >= 3 && threadIdx.x < 9) den[threadIdx.x] = 0.f;
 }
 
 struct BaseArgs {
@@ -358,7 +365,7 @@ static LossLayout loss_layout(int B, int C, int H, int W, int multiscale, int gr
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += (n + 63) / 64 * 64; return o; };
   L.NUM = take(NSLOT * SLOT_STRIDE);
-  L.PART = take((int64_t)B * 4);
+  L.PART = take((int64_t)B * 4 * 16);       // up to 16 row chunks per sample
   int gd = grad_ds < 1 ? 1 : grad_ds;
   for (int s = 0; s < L.ns; ++s) {
     L.h[s] = s == 0 ? H : L.h[s - 1] / 2;
@@ -405,8 +412,12 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
   if (L.ns == 1) {
     const bool want_mg = lam_grad != 0.f;
     if (want_mg && (L.gh[0] < 1 || L.gw[0] < 1)) { set_error("sx_loss_prepare: grid too small for grad_ds"); return SX_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(prepare1_kernel, dim3(B), dim3(256), 0, st, mask, w, H, W, L.gds[0], want_mg ? 1 : 0, ws + L.MG[0], ws + L.PART);
-    hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(64), 0, st, ws + L.PART, B, den);
+    const int k = L.gds[0];
+    int chunks = std::max(1, std::min(16, H / std::max(8, k)));
+    const int rows_per = cdiv(cdiv(H, chunks), k) * k;
+    chunks = cdiv(H, rows_per);
+    hipLaunchKernelGGL(prepare1_kernel, dim3(chunks, B), dim3(256), 0, st, mask, w, H, W, k, want_mg ? 1 : 0, ws + L.MG[0], ws + L.PART, rows_per);
+    hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(256), 0, st, ws + L.PART, B * chunks, den);
     SX_LAUNCH_CHECK("loss_prepare");
     return SX_OK;
   }
