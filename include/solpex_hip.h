@@ -302,8 +302,9 @@ int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const 
 #define SX_BWD_ACCUMULATE   2  /* add into `grads` instead of overwriting   */
 #define SX_BWD_ZERO_DPARAMS 4  /* zero FILM_DPARAMS first (the first backward half to run sets it) */
 #define SX_BWD_DEFER_FILM   8  /* pass to BOTH halves: the decoder's FiLM generators (their parameter gradients and their
-                                  share of FILM_DPARAMS) are back-propagated inside sx_unet_encode_backward, one launch
-                                  pair for all generators; film_dec.* gradients are complete only after that call */
+                                  share of FILM_DPARAMS) and the decoder half's GroupNorm affine and bias gradients are finished
+                                  inside sx_unet_encode_backward (one launch for all of them); film_dec.* and
+                                  decoders.*.net.{1,4}.*, up_convs.*.bias, out.bias gradients are complete only after that call */
 int     sx_unet_decode_backward(const sx_unet_desc* d, const float* const* params, float* const* grads,
                                 const void* wpack, void* ws, const float* film_params,
                                 const float* const* drop, int flags, void* stream);

@@ -609,6 +609,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(sx_conv_forward(dt, SX_CONVT_BWD, B, p.H[l + 1], p.W[l + 1], p.C[l], p.C[l + 1], at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l],
                            at(wpack, p.upb[j]), nullptr, at(ws, prev.dO), p.C[l + 1], p.H[l + 1], p.W[l + 1], 0, nullptr, 0, stream));
   }
+  if (flags & SX_BWD_DEFER_FILM) wq.gn.clear();      // GroupNorm affine and bias gradients of this half: reduced by the encoder half's launch
   SX_TRY(wq.finish());
   // SX_BWD_DEFER_FILM: the decoder's FiLM generators are back-propagated by sx_unet_encode_backward together with the
   // encoder's (one launch pair per step instead of two; each pair is ~45 us of latency-bound work on a few CUs)
@@ -644,6 +645,16 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
                                     at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
     SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, wq, st));
+  }
+  if (wg && (flags & SX_BWD_DEFER_FILM))
+    for (int k = D + 1; k <= 2 * D; ++k) {       // decoder blocks: their per-sample sums are still in the workspace
+      const BlockBuf& b = p.blk[k];
+      wq.add_gn((const float*)at(ws, b.sums2), grads[b.pidx + 4], grads[b.pidx + 5], b.C);
+      wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
+    }
+  if (wg && (flags & SX_BWD_DEFER_FILM)) {       // ... and so are the head / transposed-conv bias sums
+    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch);
+    for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
   }
   SX_TRY(wq.finish());
   if (film) SX_TRY(film_run_backward(p, 0, (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1, params, grads, ws, film_params, flags, st));

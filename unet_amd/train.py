@@ -72,10 +72,14 @@ class TrainEngine:
         self.cfg = model._cfg
         names = model._names
         # arena order: decoder half first (its bucket is all-reduced while the encoder's backward runs).  The decoder's
-        # FiLM generators belong to the second bucket: their gradients come out of sx_unet_encode_backward
+        # FiLM generators and GroupNorm affine parameters belong to the second bucket: their gradients come out of
+        # sx_unet_encode_backward
         # (SX_BWD_DEFER_FILM: one FiLM backward launch pair per step)
-        dec = [names[i] for i in model._dec_idx if not names[i].startswith("film_dec.")]
-        enc = [names[i] for i in model._dec_idx if names[i].startswith("film_dec.")] + [names[i] for i in model._enc_idx]
+        def late(n):       # decoder-half parameters whose gradients SX_BWD_DEFER_FILM finishes in the encoder half
+            return (n.startswith("film_dec.") or (n.startswith("decoders.") and (".net.1." in n or ".net.4." in n))
+                    or n == "out.bias" or (n.startswith("up_convs.") and n.endswith(".bias")))
+        dec = [names[i] for i in model._dec_idx if not late(names[i])]
+        enc = [names[i] for i in model._dec_idx if late(names[i])] + [names[i] for i in model._enc_idx]
         self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + enc)
         self.n_dec = self.slots[enc[0]][0] if enc else self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
