@@ -269,7 +269,9 @@ typedef struct sx_unet_desc {
   int32_t in_ch, out_ch, base, depth, groups_gn, P, film_hidden;
   int32_t B, H, W;
   int32_t dtype;      /* sx_dtype of activations / packed weights */
-  int32_t use_film;   /* FiLM applied (params given and P > 0) */
+  int32_t use_film;   /* 0: no FiLM; 1: FiLM applied (params given and P > 0); 2: as 1, and the caller promises that
+                         sx_unet_encode and sx_unet_decode get the SAME film_params: encode then evaluates every
+                         generator in one launch and decode none */
 } sx_unet_desc;
 
 typedef enum sx_unet_tensor {

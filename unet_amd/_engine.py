@@ -49,7 +49,7 @@ _TORCH_DT = {L.SX_F32: torch.float32, L.SX_BF16: torch.bfloat16}
 class UNetSession:
     """One (config, batch shape, dtype) instance of the HIP U-Net: workspace + packed weights."""
 
-    def __init__(self, cfg, B, H, W, dtype, use_film, device, wpack=None):
+    def __init__(self, cfg, B, H, W, dtype, use_film, device, wpack=None, film_shared=False):
         self.lib = L.lib()
         self.cfg = dict(cfg)
         self.device = torch.device(device)
@@ -58,7 +58,7 @@ class UNetSession:
         self.esz = 2 if dtype == L.SX_BF16 else 4
         d = L.UNetDesc(in_ch=cfg["in_ch"], out_ch=cfg["out_ch"], base=cfg["base"], depth=cfg["depth"],
                        groups_gn=cfg["groups_gn"], P=cfg["P"], film_hidden=cfg["film_hidden"], B=B, H=H, W=W,
-                       dtype=dtype, use_film=1 if use_film else 0)
+                       dtype=dtype, use_film=(2 if film_shared else 1) if use_film else 0)
         self.desc = d
         self.B, self.H, self.W = B, H, W
         self.use_film = bool(use_film)

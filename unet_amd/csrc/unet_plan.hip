@@ -517,7 +517,9 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
   }
   SX_TRY(sx_pack_input(dt, x, sb, sc, sh, sw, B, d->in_ch, d->H, d->W, at(ws, p.X0), p.in_pad, stream));
-  if (film) SX_TRY(film_run_forward(p, 0, D + 1, params, ws, film_params, st));
+  // use_film == 2: encode and decode of this descriptor always see the same film_params, so every generator (the
+  // decoder's too) is evaluated here in one launch and sx_unet_decode launches none
+  if (film) SX_TRY(film_run_forward(p, 0, d->use_film == 2 ? 2 * D + 1 : D + 1, params, ws, film_params, st));
   for (int k = 0; k <= D; ++k) {
     SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st));
     if (k < D)
@@ -540,7 +542,7 @@ extern "C" int sx_unet_decode(const sx_unet_desc* d, const float* const* params,
     hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(p.stats_end - b0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
   }
-  if (film) SX_TRY(film_run_forward(p, D + 1, 2 * D + 1, params, ws, film_params, st));
+  if (film && d->use_film != 2) SX_TRY(film_run_forward(p, D + 1, 2 * D + 1, params, ws, film_params, st));
   for (int j = 0; j < D; ++j) {
     const int l = D - 1 - j, k = D + 1 + j;
     const BlockBuf& prev = p.blk[k - 1];   // bottleneck for j = 0, else decoder j-1

@@ -80,7 +80,7 @@ class _Problem:
         from ._engine import UNetSession
         params = model._ordered_params()
         dev = params[0].device
-        self.sess = UNetSession(model._cfg, B, H, W, dtype, True, dev)
+        self.sess = UNetSession(model._cfg, B, H, W, dtype, True, dev, film_shared=True)
         self.sess.set_params(params)
         self.sess.pack_weights()
         self.B = B

@@ -110,7 +110,7 @@ class TrainEngine:
         if ent is None:
             any_sess = next(iter(self._sessions.values()))[0] if self._sessions else None
             sess = UNetSession(self.cfg, B, H, W, self.sx_dtype, use_film, self.device,
-                               wpack=None if any_sess is None else any_sess.wpack)
+                               wpack=None if any_sess is None else any_sess.wpack, film_shared=True)
             sess.set_params(self.params)
             sess.set_grads(self.grads)
             o = self.loss_opts
