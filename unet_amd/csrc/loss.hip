@@ -303,6 +303,191 @@ __global__ void sobel_bwd_kernel(const float* __restrict__ ux, const float* __re
   }
 }
 
+// ---------------------------------------------------------------- single-scale fused path (multiscale = 0, grad_ds > 1)
+// One thread per grad_ds x grad_ds pooling window and all C channels.
+//   base_pool_kernel : base + edge terms (as base_kernel) straight from the NHWC prediction, the planar base gradient,
+//                      and the pooled prediction / target planes of the gradient term  (replaces to_planar, base, 2 x avgpool)
+//   grad_out_kernel  : transposed Sobel of (ux, uy) once per window, added to the base gradient of its pixels and written
+//                      as the NHWC d_pred                                                (replaces sobel_bwd, from_planar)
+static constexpr int FUSE_MAXC = 16;
+struct FuseArgs {
+  const void* pred; int ld;
+  const float* t; const float* m; const float* w; const float* cw;
+  float* g; float* pg; float* tg; float* num;
+  const float* ux; const float* uy; void* dpred; int dld; float scale;
+  int B, C, H, W, k;
+  int kind; float beta, lam_w;
+  const float* den;
+};
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+
+// 2 x 2 windows (grad_ds = 2, the production setting), C <= 8, even W: both pixels of a window row move as one 8-byte
+// (fp32 planes) or two 16-byte (NHWC bf16) accesses.  FAST = false: any window size / channel count, scalar accesses.
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
+  constexpr int MC = FAST ? 8 : FUSE_MAXC;
+  float v[3] = {0.f, 0.f, 0.f};
+  const float scw = cw_sum(a.cw, a.C);
+  const float cb = 1.0f / fmaxf(a.den[0] * scw, 1e-8f);
+  const float ce = (a.w && a.lam_w != 0.f) ? a.lam_w / fmaxf(a.den[1] * scw, 1e-8f) : 0.f;
+  const int k = FAST ? 2 : a.k;
+  const int gh = a.H / k, gw = a.W / k, hw = a.H * a.W;
+  const float inv = 1.0f / (float)(k * k);
+  const T* pred = reinterpret_cast<const T*>(a.pred);
+  const int64_t n = (int64_t)a.B * gh * gw;
+  float cwv[MC];
+#pragma unroll
+  for (int c = 0; c < MC; ++c) cwv[c] = (c < a.C) ? (a.cw ? a.cw[c] : 1.f) : 0.f;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % gw);
+    const int y = (int)((i / gw) % gh);
+    const int b = (int)(i / ((int64_t)gw * gh));
+    float sp[MC], st[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) { sp[c] = 0.f; st[c] = 0.f; }
+    if constexpr (FAST) {
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int px = (y * 2 + dy) * a.W + x * 2;
+        const f32x2_ mm = *reinterpret_cast<const f32x2_*>(a.m + (int64_t)b * hw + px);
+        f32x2_ ww = {0.f, 0.f};
+        if (a.w) ww = *reinterpret_cast<const f32x2_*>(a.w + px);
+        const T* pp = pred + ((int64_t)b * hw + px) * a.ld;
+        const f32x8 p0 = load8(pp), p1 = load8(pp + a.ld);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (c < a.C) {
+            const int64_t e = ((int64_t)b * a.C + c) * hw + px;
+            const f32x2_ tt = *reinterpret_cast<const f32x2_*>(a.t + e);
+            const float pr[2] = {p0.v[c], p1.v[c]};
+            f32x2_ go;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const float d = pr[dx] - tt[dx];
+              const float l = px_val(a.kind, d, a.beta);
+              v[0] += l * mm[dx] * cwv[c];
+              v[1] += l * mm[dx] * ww[dx] * cwv[c];
+              v[2] += fabsf(d) * mm[dx];
+              go[dx] = px_grad(a.kind, d, a.beta) * mm[dx] * cwv[c] * (cb + ce * ww[dx]);
+              sp[c] += pr[dx];
+              st[c] += tt[dx];
+            }
+            if (a.g) *reinterpret_cast<f32x2_*>(a.g + e) = go;
+          }
+        }
+      }
+    } else {
+      for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) {
+          const int px = (y * k + dy) * a.W + x * k + dx;
+          const float mm = a.m[(int64_t)b * hw + px];
+          const float ww = a.w ? a.w[px] : 0.f;
+          const T* pp = pred + ((int64_t)b * hw + px) * a.ld;
+#pragma unroll
+          for (int c = 0; c < MC; ++c) {
+            if (c < a.C) {
+              const int64_t e = ((int64_t)b * a.C + c) * hw + px;
+              const float pr = to_f32(pp[c]), tt = a.t[e];
+              const float d = pr - tt;
+              const float l = px_val(a.kind, d, a.beta);
+              v[0] += l * mm * cwv[c];
+              v[1] += l * mm * ww * cwv[c];
+              v[2] += fabsf(d) * mm;
+              if (a.g) a.g[e] = px_grad(a.kind, d, a.beta) * mm * cwv[c] * (cb + ce * ww);
+              sp[c] += pr;
+              st[c] += tt;
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+      if (c < a.C) {
+        const int64_t q = (((int64_t)b * a.C + c) * gh + y) * gw + x;
+        a.pg[q] = sp[c] * inv;
+        a.tg[q] = st[c] * inv;
+      }
+  }
+  __shared__ float red[12];
+  block_sum<3>(v, red);
+  if (threadIdx.x == 0) {
+    float* num = slot_of(a.num);
+    atomicAdd(num + 0, v[0]);
+    atomicAdd(num + 1, v[1]);
+    atomicAdd(num + 2, v[2]);
+  }
+}
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a) {
+  constexpr int MC = FAST ? 8 : FUSE_MAXC;
+  const int k = FAST ? 2 : a.k;
+  const int gh = a.H / k, gw = a.W / k, hw = a.H * a.W;
+  const float inv = 1.0f / (float)(k * k);
+  T* out = reinterpret_cast<T*>(a.dpred);
+  const int64_t n = (int64_t)a.B * gh * gw;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % gw);
+    const int y = (int)((i / gw) % gh);
+    const int b = (int)(i / ((int64_t)gw * gh));
+    float d[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      d[c] = 0.f;
+      if (c < a.C) {
+        const float* X = a.ux + ((int64_t)b * a.C + c) * gh * gw;
+        const float* Y = a.uy + ((int64_t)b * a.C + c) * gh * gw;
+        float t = 0.f;
+        t += -1.f * at0(X, gh, gw, y + 1, x + 1) + 1.f * at0(X, gh, gw, y + 1, x - 1);
+        t += -2.f * at0(X, gh, gw, y, x + 1) + 2.f * at0(X, gh, gw, y, x - 1);
+        t += -1.f * at0(X, gh, gw, y - 1, x + 1) + 1.f * at0(X, gh, gw, y - 1, x - 1);
+        t += -1.f * at0(Y, gh, gw, y + 1, x + 1) - 2.f * at0(Y, gh, gw, y + 1, x) - 1.f * at0(Y, gh, gw, y + 1, x - 1);
+        t += 1.f * at0(Y, gh, gw, y - 1, x + 1) + 2.f * at0(Y, gh, gw, y - 1, x) + 1.f * at0(Y, gh, gw, y - 1, x - 1);
+        d[c] = t * inv;
+      }
+    }
+    if constexpr (FAST) {       // dld == 8: one 16-byte store per pixel, the plane gradient read as 8-byte pairs
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int px = (y * 2 + dy) * a.W + x * 2;
+        f32x8 o0, o1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          f32x2_ gg = {0.f, 0.f};
+          if (c < a.C) gg = *reinterpret_cast<const f32x2_*>(a.g + ((int64_t)b * a.C + c) * hw + px);
+          o0.v[c] = c < a.C ? a.scale * (d[c] + gg[0]) : 0.f;
+          o1.v[c] = c < a.C ? a.scale * (d[c] + gg[1]) : 0.f;
+        }
+        T* dst = out + ((int64_t)b * hw + px) * 8;
+        store8(dst, o0);
+        store8(dst + 8, o1);
+      }
+    } else {
+      for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) {
+          const int px = (y * k + dy) * a.W + x * k + dx;
+          T* dst = out + ((int64_t)b * hw + px) * a.dld;
+          for (int c0 = 0; c0 < a.dld; c0 += 8) {          // dld % 8 == 0 (checked on the host): 16-byte stores, zero fill
+            f32x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int c = c0 + e;
+              float val = 0.f;
+              if (c < a.C) {
+#pragma unroll
+                for (int cc = 0; cc < MC; ++cc) if (cc == c) val = d[cc];
+                val = a.scale * (val + a.g[((int64_t)b * a.C + c) * hw + px]);
+              }
+              o.v[e] = val;
+            }
+            store8(dst + c0, o);
+          }
+        }
+    }
+  }
+}
+
 // fine[p] += coarse[q(p)] / 4   (avg_pool2d(2) backward), floor semantics: trailing odd row/col untouched
 __global__ void unpool2_add_kernel(const float* __restrict__ coarse, float* __restrict__ fine, int64_t planes, int h, int w, int hf, int wf) {
   const int64_t n = planes * h * w;
@@ -468,6 +653,46 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
   hipError_t e = hipMemsetAsync(num, 0, NSLOT * SLOT_STRIDE * sizeof(float), st);
   if (e != hipSuccess) return hip_fail(e, "memset(num)");
   const bool want_grad = d_pred != nullptr;
+  if (L.ns == 1 && lam_grad != 0.f && L.gds[0] > 1 && H % L.gds[0] == 0 && W % L.gds[0] == 0 && C <= FUSE_MAXC &&
+      (!want_grad || dpred_ld % 8 == 0)) {
+    const int gd = L.gds[0], gh = L.gh[0], gw = L.gw[0];
+    FuseArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.pred = pred; fa.ld = pred_ld; fa.t = target; fa.m = mask; fa.w = w; fa.cw = cw;
+    fa.g = want_grad ? ws + L.G[0] : nullptr; fa.pg = ws + L.PG[0]; fa.tg = ws + L.TG[0]; fa.num = num;
+    fa.ux = ws + L.UX[0]; fa.uy = ws + L.UY[0]; fa.dpred = d_pred; fa.dld = dpred_ld; fa.scale = grad_scale;
+    fa.B = B; fa.C = C; fa.H = H; fa.W = W; fa.k = gd; fa.kind = base_kind; fa.beta = huber_beta; fa.lam_w = lam_w; fa.den = den;
+    const int64_t nwin = (int64_t)B * gh * gw, ng = nwin * C;
+    // fast instance: 2 x 2 windows, <= 8 channels in 8-wide NHWC rows, 8-byte aligned plane rows
+    const bool fast = gd == 2 && C <= 8 && pred_ld == 8 && (!want_grad || dpred_ld == 8) && W % 2 == 0 &&
+                      ((uintptr_t)target % 8) == 0 && ((uintptr_t)mask % 8) == 0 && (!w || ((uintptr_t)w % 8) == 0) &&
+                      ((uintptr_t)pred % 16) == 0 && (!want_grad || ((uintptr_t)d_pred % 16) == 0);
+#define SX_FUSE_LAUNCH(KERN)                                                                                    \
+    do {                                                                                                        \
+      if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(nwin)), dim3(256), 0, st, fa);   \
+                              else hipLaunchKernelGGL((KERN<bf16, false>), dim3(gsz(nwin)), dim3(256), 0, st, fa); }     \
+      else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(nwin)), dim3(256), 0, st, fa);                   \
+             else hipLaunchKernelGGL((KERN<float, false>), dim3(gsz(nwin)), dim3(256), 0, st, fa); }                     \
+    } while (0)
+    SX_FUSE_LAUNCH(base_pool_kernel);
+    SobelArgs sa;
+    sa.p = ws + L.PG[0]; sa.t = ws + L.TG[0]; sa.m = ws + L.MG[0]; sa.cw = cw;
+    sa.ux = want_grad ? ws + L.UX[0] : nullptr; sa.uy = want_grad ? ws + L.UY[0] : nullptr;
+    sa.num = num + 3; sa.B = B; sa.C = C; sa.h = gh; sa.w = gw;
+    sa.magnitude = grad_magnitude; sa.kind = grad_kind; sa.beta = huber_beta;
+    sa.den = den; sa.cgl = lam_grad;
+    hipLaunchKernelGGL(sobel_fwd_kernel, dim3(gsz(ng)), dim3(256), 0, st, sa);
+    if (want_grad) {
+      SX_FUSE_LAUNCH(grad_out_kernel);
+    }
+#undef SX_FUSE_LAUNCH
+    FinalArgs f;
+    f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = 1; f.lam_w = lam_w; f.lam_grad = lam_grad;
+    f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+    SX_LAUNCH_CHECK("loss_forward_backward");
+    return SX_OK;
+  }
   {
     const int64_t n = (int64_t)B * C * H * W;
     if (dtype == SX_BF16) hipLaunchKernelGGL(to_planar_kernel<bf16>, dim3(gsz(n)), dim3(256), 0, st, (const bf16*)pred, pred_ld, ws + L.P[0], B, C, H, W);
