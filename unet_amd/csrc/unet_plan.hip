@@ -512,7 +512,8 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
   const int dt = d->dtype, B = d->B, D = p.depth;
   // clear the encoder's GN statistics (blocks 0..D are laid out first)
   {
-    const int64_t b0 = p.blk[0].st1, b1 = p.blk[D + 1].st1;
+    // use_film == 2 pairs every decode with the encode before it: the decoder's statistics are cleared here too
+    const int64_t b0 = p.blk[0].st1, b1 = d->use_film == 2 ? p.stats_end : p.blk[D + 1].st1;
     hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(b1 - b0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
   }
@@ -537,7 +538,7 @@ extern "C" int sx_unet_decode(const sx_unet_desc* d, const float* const* params,
   SX_REQUIRE(!film || film_params, "sx_unet_decode: FiLM requested without params");
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
-  {
+  if (d->use_film != 2) {
     const int64_t b0 = p.blk[D + 1].st1;
     hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(p.stats_end - b0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
@@ -572,8 +573,9 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
   {
-    // decoder sums, bias scratch and (optionally) dparams are contiguous: one memset
-    const int64_t s0 = p.blk[D + 1].sums1;
+    // decoder sums, bias scratch and (optionally) dparams are contiguous: one memset. SX_BWD_DEFER_FILM promises that
+    // sx_unet_encode_backward follows on this workspace, so the encoder's sums (laid out just before) are cleared too
+    const int64_t s0 = (flags & SX_BWD_DEFER_FILM) ? p.blk[0].sums1 : p.blk[D + 1].sums1;
     const int64_t s1 = (flags & SX_BWD_ZERO_DPARAMS) ? p.dparams + (int64_t)align_up((size_t)B * std::max(1, d->P) * 4, 256) : p.bwd_zero_end;
     hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(sums)");
@@ -631,7 +633,8 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
   const int dt = d->dtype, B = d->B, D = p.depth;
   {
     const int64_t s0 = p.blk[0].sums1, s1 = p.blk[D + 1].sums1;
-    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
+    hipError_t e = hipSuccess;
+    if (!(flags & SX_BWD_DEFER_FILM)) e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);   // else: cleared by the decoder half
     if (e != hipSuccess) return hip_fail(e, "memset(sums)");
     if (flags & SX_BWD_ZERO_DPARAMS) {
       e = hipMemsetAsync(at(ws, p.dparams), 0, (size_t)B * std::max(1, d->P) * 4, st);
