@@ -52,10 +52,10 @@ __device__ __forceinline__ void gn_coeffs(const ActArgs& a, int b, float* rs, fl
 // ---------------------------------------------------------------- forward
 // MODE 0: out0 = silu(gn(Y))                      (first GN of the block)
 // MODE 1: R = (silu(gn(Y)) + S) * drop ; out0 = R * gf + bf ; out1 = R (if non-null)
-template <typename T, int MODE>
+template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_fwd_kernel(ActArgs a) {
-  __shared__ float sc[MAXC], sh[MAXC];
-  __shared__ float fg[MODE ? MAXC : 1], fb[MODE ? MAXC : 1], dr[MODE ? MAXC : 1];
+  __shared__ float sc[CMAX], sh[CMAX];            // CMAX = 256 instances keep LDS small enough for 8 waves per SIMD
+  __shared__ float fg[MODE ? CMAX : 1], fb[MODE ? CMAX : 1], dr[MODE ? CMAX : 1];
   const int b = blockIdx.y;
   gn_coeffs(a, b, sc, sh);
   __syncthreads();
@@ -103,10 +103,14 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(ActArgs a) {
 // ---------------------------------------------------------------- backward, phase 1
 // sums[b][c] += { sum dz*n_hat, sum dz, sum dO*R, sum dO }   (last two only for MODE 1)
 //   dz = dO * gf * drop * silu'(z)
-template <typename T, int MODE>
+// A thread owns a 4-channel slot here (not 8): sixteen accumulators and sixteen loop-invariant coefficients keep
+// the kernel near 64 VGPRs, and this read-only pass needs the waves (measured: 3 -> 4 waves per SIMD was -17 %).
+// The per-channel factor gf*drop is applied to the finished sums, not per pixel.
+template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
-  __shared__ float rs[MAXC], mr[MAXC], ga[MAXC], be[MAXC], fac[MAXC];
-  __shared__ float red[256 * 8];
+  constexpr int CH = 4;
+  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX];
+  __shared__ float red[256 * CH];
   const int b = blockIdx.y;
   gn_coeffs(a, b, rs, mr);
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
@@ -120,60 +124,79 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
     fac[c] = f;
   }
   __syncthreads();
-  const int slots = a.C >> 3;
-  const int lanes = 256 / slots;                 // pixel lanes per block (slots <= 256)
+  const int NT = blockDim.x;
+  const int slots = a.C / CH;
+  const int lanes = NT / slots;                  // pixel lanes per block (slots <= MAXC / 4 = 256 <= NT)
   const int slot = threadIdx.x % slots, pl = threadIdx.x / slots;
-  const int c0 = slot << 3;
+  const int c0 = slot * CH;
   const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
   const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
   const T* Y = reinterpret_cast<const T*>(a.Y);
   const T* R = reinterpret_cast<const T*>(a.R);
   const T* dO = reinterpret_cast<const T*>(a.dO);
   constexpr int NS = MODE ? 4 : 2;
-  float acc[NS][8];
+  float acc[NS][CH];
 #pragma unroll
   for (int k = 0; k < NS; ++k)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    for (int e = 0; e < CH; ++e) acc[k][e] = 0.f;
   if (pl < lanes) {
     for (int64_t p = p0 + pl; p < p1; p += lanes) {
       const int64_t pix = (int64_t)b * a.HW + p;
-      f32x8 y = load8(Y + pix * a.y_ld + c0);
-      f32x8 g = load8(dO + pix * a.do_ld + c0);
-      f32x8 r;
-      if (MODE) r = load8(R + pix * a.r_ld + c0);
+      f32x4 y = load4(Y + pix * a.y_ld + c0);
+      f32x4 g = load4(dO + pix * a.do_ld + c0);
+      f32x4 r;
+      if (MODE) r = load4(R + pix * a.r_ld + c0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float nh = y.v[e] * rs[c0 + e] - mr[c0 + e];
+      for (int e = 0; e < CH; ++e) {
+        const float nh = y[e] * rs[c0 + e] - mr[c0 + e];
         const float z = nh * ga[c0 + e] + be[c0 + e];
-        const float dz = g.v[e] * fac[c0 + e] * dsiluf_(z);
+        const float dz = g[e] * dsiluf_(z);
         acc[0][e] += dz * nh;
         acc[1][e] += dz;
-        if (MODE) { acc[2][e] += g.v[e] * r.v[e]; acc[3][e] += g.v[e]; }
+        if (MODE) { acc[2][e] += g[e] * r[e]; acc[3][e] += g[e]; }
       }
     }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { acc[0][e] *= fac[c0 + e]; acc[1][e] *= fac[c0 + e]; }
   }
-  // reduce over the pixel lanes that share a slot
+  // reduce over the pixel lanes that share a slot: red = [lane][C] floats
+  const bool fold = a.C <= NT && NT % a.C == 0;   // then element j*NT + t belongs to channel t % C for every j
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[k][e];
+    for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = acc[k][e];
     __syncthreads();
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-      const int sl = c >> 3, e = c & 7;
+    if (fold) {
+      // every thread: CH fixed-stride reads (pipelined), then NT / C partials per channel
       float s = 0.f;
-      for (int l = 0; l < lanes; ++l) s += red[(l * slots + sl) * 8 + e];
-      atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, s);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s += red[j * NT + threadIdx.x];
+      __syncthreads();
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if ((int)threadIdx.x < a.C) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int q = threadIdx.x; q < NT; q += a.C) t += red[q];
+        atomicAdd(a.sums + ((int64_t)b * a.C + threadIdx.x) * 4 + k, t);
+      }
+    } else {
+      for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[l * a.C + c];
+        atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, s);
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------- backward, phase 2
 // dY = rstd * (gamma*dz - mean_g(gamma*dz) - n_hat * mean_g(gamma*dz*n_hat)) ; dR = dO*gf*drop (optional)
-template <typename T, int MODE>
+template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
-  __shared__ float rs[MAXC], mr[MAXC], ga[MAXC], be[MAXC], fac[MAXC], m1[MAXC], m2[MAXC];
+  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX], m1[CMAX], m2[CMAX], q1[CMAX], q2[CMAX];
   const int b = blockIdx.y;
   gn_coeffs(a, b, rs, mr);
   const int cpg = a.C / a.G;
@@ -187,14 +210,18 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
       if (a.drop) f *= a.drop[(int64_t)b * a.C + c];
     }
     fac[c] = f;
+    // gamma-weighted channel sums; their per-group totals are formed from LDS below (one L2 round trip per block
+    // instead of one per channel of the group)
+    const float4 sv = *reinterpret_cast<const float4*>(a.sums + ((int64_t)b * a.C + c) * 4);
+    q1[c] = ga[c] * sv.y;
+    q2[c] = ga[c] * sv.x;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
     const int gbase = (c / cpg) * cpg;
     float t1 = 0.f, t2 = 0.f;
-    for (int cc = gbase; cc < gbase + cpg; ++cc) {
-      const float* s = a.sums + ((int64_t)b * a.C + cc) * 4;
-      const float gm = a.gamma[cc];
-      t2 += gm * s[0];
-      t1 += gm * s[1];
-    }
+#pragma unroll 4
+    for (int cc = gbase; cc < gbase + cpg; ++cc) { t1 += q1[cc]; t2 += q2[cc]; }
     m1[c] = t1 * inv_n;
     m2[c] = t2 * inv_n;
   }
@@ -282,9 +309,12 @@ static int act_check(const ActArgs& a, const char* who) {
   return SX_OK;
 }
 
-static dim3 act_grid(ActArgs& a) {
-  // ~2048 blocks in total, at least 64 pixels per block
-  int chunks = std::max(1, std::min(cdiv(a.HW, 64), cdiv(2048, a.B)));
+static dim3 act_grid(ActArgs& a, int target = 2048) {
+  // ~target blocks in total with at least 64 pixels per block; small problems (few hundred blocks at that size) go down
+  // to 16 pixels per block so that the chip is covered: their time is a latency chain, not bandwidth
+  const int big = std::min(cdiv(a.HW, 64), cdiv(target, a.B));
+  const int small = std::min(cdiv(a.HW, 16), cdiv(512, a.B));
+  int chunks = std::max(1, std::max(big, small));
   a.pix_per_block = cdiv(a.HW, chunks);
   chunks = cdiv(a.HW, a.pix_per_block);
   return dim3(chunks, a.B);
@@ -294,10 +324,16 @@ static dim3 act_grid(ActArgs& a) {
 
 using namespace sx;
 
-#define SX_DISPATCH_T(dtype, KERN, MODE, grid, st, args)                                    \
-  do {                                                                                      \
-    if ((dtype) == SX_BF16) hipLaunchKernelGGL((KERN<bf16, MODE>), grid, dim3(256), 0, st, args); \
-    else hipLaunchKernelGGL((KERN<float, MODE>), grid, dim3(256), 0, st, args);             \
+#define SX_DISPATCH_T(dtype, KERN, MODE, grid, st, args)                                                   \
+  do {                                                                                                     \
+    const bool small_c = (args).C <= 256;                                                                  \
+    if ((dtype) == SX_BF16) {                                                                              \
+      if (small_c) hipLaunchKernelGGL((KERN<bf16, MODE, 256>), grid, dim3(256), 0, st, args);              \
+      else hipLaunchKernelGGL((KERN<bf16, MODE, MAXC>), grid, dim3(256), 0, st, args);                     \
+    } else {                                                                                               \
+      if (small_c) hipLaunchKernelGGL((KERN<float, MODE, 256>), grid, dim3(256), 0, st, args);             \
+      else hipLaunchKernelGGL((KERN<float, MODE, MAXC>), grid, dim3(256), 0, st, args);                    \
+    }                                                                                                      \
   } while (0)
 
 extern "C" int sx_gn_silu_forward(int dtype, int B, int HW, int C, int groups, float eps, const void* y, int y_ld,
@@ -350,8 +386,11 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   SX_TRY(act_check(a, "sx_gn_silu_backward"));
   dim3 grid = act_grid(a);
   hipStream_t st = (hipStream_t)stream;
-  if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid, st, a); }
-  else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid, st, a); }
+  // the block-output pass (four sums, three tensors) pays more per block for its combine: half as many blocks
+  dim3 grid_r = mode ? act_grid(a, 1024) : grid;
+  if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid_r, st, a); }
+  else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid_r, st, a); }
+  grid = act_grid(a);
   SX_LAUNCH_CHECK("gn_bwd_reduce");
   if (mode) { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 1, grid, st, a); }
   else { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 0, grid, st, a); }
