@@ -41,16 +41,32 @@ __global__ void unpack_output_kernel(const T* __restrict__ in, int ld, float* __
   }
 }
 
+// (slot, x, y, b) of a flat work item; 32-bit divisions when the item count allows (a 64-bit division is ~100 VALU
+// instructions, and these kernels run one item per thread: the index math sits in front of every load)
+__device__ __forceinline__ void split_item(int64_t i, bool small, int slots, int Wn, int Hn, int& c0, int& ix, int& iy, int& b) {
+  if (small) {
+    const unsigned u = (unsigned)i, q = u / (unsigned)slots, r = q / (unsigned)Wn, bb = r / (unsigned)Hn;
+    c0 = (int)(u - q * (unsigned)slots) << 3;
+    ix = (int)(q - r * (unsigned)Wn);
+    iy = (int)(r - bb * (unsigned)Hn);
+    b = (int)bb;
+  } else {
+    c0 = (int)(i % slots) << 3;
+    int64_t p = i / slots;
+    ix = (int)(p % Wn); p /= Wn;
+    iy = (int)(p % Hn);
+    b = (int)(p / Hn);
+  }
+}
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int B, int H, int W, int C) {
   const int Ho = H >> 1, Wo = W >> 1, slots = C >> 3;
   const int64_t total = (int64_t)B * Ho * Wo * slots;
+  const bool small = total < ((int64_t)1 << 32);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % slots) << 3;
-    int64_t p = i / slots;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+    int c0, ox, oy, b;
+    split_item(i, small, slots, Wo, Ho, c0, ox, oy, b);
     const T* src = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * x_ld + c0;
     f32x8 v00 = load8(src), v01 = load8(src + x_ld), v10 = load8(src + (int64_t)W * x_ld), v11 = load8(src + (int64_t)(W + 1) * x_ld);
     f32x8 o;
@@ -68,12 +84,10 @@ __global__ void maxpool_bwd_add_kernel(const T* __restrict__ x, int x_ld, const 
                                        int B, int H, int W, int C) {
   const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1, slots = C >> 3;
   const int64_t total = (int64_t)B * Hw * Ww * slots;
+  const bool small = total < ((int64_t)1 << 32);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % slots) << 3;
-    int64_t p = i / slots;
-    const int wx = (int)(p % Ww); p /= Ww;
-    const int wy = (int)(p % Hw);
-    const int b = (int)(p / Hw);
+    int c0, wx, wy, b;
+    split_item(i, small, slots, Ww, Hw, c0, wx, wy, b);
     const bool pooled = wy < Ho && wx < Wo;
     f32x8 v[4], g;
     int best[8];

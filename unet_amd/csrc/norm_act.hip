@@ -71,16 +71,19 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(ActArgs a) {
   }
   __syncthreads();
   const int slots = a.C >> 3;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
-  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
-  const int64_t n_items = (p1 - p0) * slots;
+  // 32-bit item arithmetic inside the block (pix_per_block * slots is far below 2^31); 64-bit only for the pixel base
+  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p1 = min(a.HW, p0 + a.pix_per_block);
+  const unsigned n_items = (unsigned)(p1 - p0) * (unsigned)slots;
+  const int64_t pbase = (int64_t)b * a.HW + p0;
   const T* Y = reinterpret_cast<const T*>(a.Y);
   const T* S = reinterpret_cast<const T*>(a.S);
   T* O0 = reinterpret_cast<T*>(a.out0);
   T* O1 = reinterpret_cast<T*>(a.out1);
-  for (int64_t it = threadIdx.x; it < n_items; it += blockDim.x) {
-    const int64_t pix = (int64_t)b * a.HW + p0 + it / slots;
-    const int c0 = (int)(it % slots) << 3;
+  for (unsigned it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const unsigned pq = it / (unsigned)slots;
+    const int64_t pix = pbase + pq;
+    const int c0 = (int)(it - pq * (unsigned)slots) << 3;
     f32x8 y = load8(Y + pix * a.y_ld + c0);
     f32x8 o;
     if (MODE == 0) {
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
   const int lanes = NT / slots;                  // pixel lanes per block (slots <= MAXC / 4 = 256 <= NT)
   const int slot = threadIdx.x % slots, pl = threadIdx.x / slots;
   const int c0 = slot * CH;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
-  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
+  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p1 = min(a.HW, p0 + a.pix_per_block);
   const T* Y = reinterpret_cast<const T*>(a.Y);
   const T* R = reinterpret_cast<const T*>(a.R);
   const T* dO = reinterpret_cast<const T*>(a.dO);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) acc[k][e] = 0.f;
   if (pl < lanes) {
-    for (int64_t p = p0 + pl; p < p1; p += lanes) {
+    for (int p = p0 + pl; p < p1; p += lanes) {
       const int64_t pix = (int64_t)b * a.HW + p;
       f32x4 y = load4(Y + pix * a.y_ld + c0);
       f32x4 g = load4(dO + pix * a.do_ld + c0);
@@ -227,16 +230,18 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
   }
   __syncthreads();
   const int slots = a.C >> 3;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pix_per_block;
-  const int64_t p1 = min((int64_t)a.HW, p0 + a.pix_per_block);
-  const int64_t n_items = (p1 - p0) * slots;
+  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p1 = min(a.HW, p0 + a.pix_per_block);
+  const unsigned n_items = (unsigned)(p1 - p0) * (unsigned)slots;
+  const int64_t pbase = (int64_t)b * a.HW + p0;
   const T* Y = reinterpret_cast<const T*>(a.Y);
   const T* dO = reinterpret_cast<const T*>(a.dO);
   T* dY = reinterpret_cast<T*>(a.out0);
   T* dR = reinterpret_cast<T*>(a.out1);
-  for (int64_t it = threadIdx.x; it < n_items; it += blockDim.x) {
-    const int64_t pix = (int64_t)b * a.HW + p0 + it / slots;
-    const int c0 = (int)(it % slots) << 3;
+  for (unsigned it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const unsigned pq = it / (unsigned)slots;
+    const int64_t pix = pbase + pq;
+    const int c0 = (int)(it - pq * (unsigned)slots) << 3;
     f32x8 y = load8(Y + pix * a.y_ld + c0);
     f32x8 g = load8(dO + pix * a.do_ld + c0);
     f32x8 o, r;
