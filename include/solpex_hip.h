@@ -131,6 +131,12 @@ int sx_block_out_forward(int dtype, int B, int HW, int C, int groups, float eps,
                          const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
                          const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
                          void* r_out, int r_ld, void* stream);
+/* sx_block_out_forward followed by nn.MaxPool2d(2) of `out` (models.py:177,181: every encoder block's output is pooled),
+ * in one pass over the block; H and W must be even, `pool` is [B][H/2][W/2] with row pitch pool_ld. */
+int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, int groups, float eps, const void* y2, int y_ld,
+                              const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                              const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                              void* r_out, int r_ld, void* pool, int pool_ld, void* stream);
 int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
                         int y_ld, const float* stats, const float* gamma, const float* beta,
                         const void* d_out, int do_ld, const void* r, int r_ld, const float* film_g,

@@ -339,6 +339,48 @@ def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cc,film", [(2, 16, 8, 16, True), (3, 6, 10, 24, False), (2, 32, 16, 64, True), (1, 8, 8, 512, True)])
+def test_block_out_pool_forward_is_block_out_then_maxpool(L, dtype, B, H, W, Cc, film):
+    """The fused encoder-block epilogue against the two calls it replaces: out, R and the pooled tensor bit-identical
+    (strided `out`, as inside the virtual concat)."""
+    g = torch.Generator().manual_seed(Cc + H)
+    G = 8
+    y2 = q(torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.3, dtype)
+    s = q(torch.randn(B, Cc, H, W, generator=g), dtype)
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda()
+    beta = (0.2 * torch.randn(Cc, generator=g)).cuda()
+    gf = (1 + 0.3 * torch.randn(B, Cc, generator=g)).cuda().contiguous()
+    bf = (0.3 * torch.randn(B, Cc, generator=g)).cuda().contiguous()
+    drop = ((torch.rand(B, Cc, generator=g) > 0.3).float() / 0.7).cuda().contiguous()
+    yg = y2.view(B, G, -1)
+    stats = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], -1).cuda().contiguous()
+    yd, sd = nhwc(y2, dtype), nhwc(s, dtype)
+    lib = L.lib()
+    res = []
+    for fused in (False, True):
+        out = torch.zeros(B, H, W, 2 * Cc, dtype=tdt(dtype), device="cuda")      # left half of a concat buffer
+        Rd = torch.zeros(B, H, W, Cc, dtype=tdt(dtype), device="cuda")
+        pool = torch.zeros(B, H // 2, W // 2, Cc, dtype=tdt(dtype), device="cuda")
+        fg, fb, dr = (L.ptr(gf), L.ptr(bf), L.ptr(drop)) if film else (None, None, None)
+        if fused:
+            L.check(lib.sx_block_out_pool_forward(dtype, B, H, W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                                  L.ptr(sd), Cc, fg, fb, dr, L.ptr(out), 2 * Cc, L.ptr(Rd), Cc, L.ptr(pool), Cc,
+                                                  L.stream_ptr()))
+        else:
+            L.check(lib.sx_block_out_forward(dtype, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                             L.ptr(sd), Cc, fg, fb, dr, L.ptr(out), 2 * Cc, L.ptr(Rd), Cc, L.stream_ptr()))
+            L.check(lib.sx_maxpool2_forward(dtype, B, H, W, Cc, L.ptr(out), 2 * Cc, L.ptr(pool), Cc, L.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append((out.float().cpu(), Rd.float().cpu(), pool.float().cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # odd sizes are refused (the plan then keeps the two calls)
+    assert lib.sx_block_out_pool_forward(dtype, B, H + 1, W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                         L.ptr(sd), Cc, None, None, None, L.ptr(out), 2 * Cc, None, Cc, L.ptr(pool), Cc,
+                                         L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 8, 6, 16), (2, 7, 5, 8)])
 def test_maxpool_forward_backward_first_max_ties(L, dtype, B, H, W, Cc):
     g = torch.Generator().manual_seed(3)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sx_conv_wgrad": (_i, [_i] * 9 + [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p]),
     "sx_gn_silu_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p]),
     "sx_block_out_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
+    "sx_block_out_pool_forward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
     "sx_gn_silu_backward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i,
                                  _p, _i, _p, _p, _i, _p]),
     "sx_pack_input": (_i, [_i, _p, _l, _l, _l, _l, _i, _i, _i, _i, _p, _i, _p]),

@@ -33,6 +33,7 @@ struct ActArgs {
   int B, HW, C, G;
   float eps;
   int pix_per_block;
+  int W; void* pool; int p_ld;    // fused 2x2 max-pool of out0 (act_fwd_pool_kernel)
 };
 
 // per-channel GN coefficients of sample b into LDS: n_hat = y * rs[c] - mr[c]; z = n_hat * ga[c] + be[c]
@@ -100,6 +101,62 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(ActArgs a) {
       store8(O0 + pix * a.o0_ld + c0, o);
       if (O1) store8(O1 + pix * a.o1_ld + c0, r);
     }
+  }
+}
+
+// MODE 1 fused with nn.MaxPool2d(2) of its output (encoder blocks; H and W even): a thread owns one 2x2 window x 8
+// channels, writes the four outputs (and R) and their maximum.  max(round(o)) == round(max(o)), so the pooled tensor is
+// bit-identical to pooling the stored bf16 output.  pix_per_block counts windows here.
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void act_fwd_pool_kernel(ActArgs a) {
+  __shared__ float sc[CMAX], sh[CMAX], fg[CMAX], fb[CMAX], dr[CMAX];
+  const int b = blockIdx.y;
+  gn_coeffs(a, b, sc, sh);
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const float r = sc[c], m = sh[c], ga = a.gamma[c];
+    sc[c] = r * ga;
+    sh[c] = a.beta[c] - m * ga;
+    fg[c] = a.gf ? a.gf[(int64_t)b * a.C + c] : 1.f;
+    fb[c] = a.bf ? a.bf[(int64_t)b * a.C + c] : 0.f;
+    dr[c] = a.drop ? a.drop[(int64_t)b * a.C + c] : 1.f;
+  }
+  __syncthreads();
+  const int slots = a.C >> 3, Wo = a.W >> 1, nwin = a.HW >> 2;
+  const int w0 = blockIdx.x * a.pix_per_block;
+  const int w1 = min(nwin, w0 + a.pix_per_block);
+  const unsigned n_items = (unsigned)(w1 - w0) * (unsigned)slots;
+  const T* Y = reinterpret_cast<const T*>(a.Y);
+  const T* S = reinterpret_cast<const T*>(a.S);
+  T* O0 = reinterpret_cast<T*>(a.out0);
+  T* O1 = reinterpret_cast<T*>(a.out1);
+  T* P = reinterpret_cast<T*>(a.pool);
+  for (unsigned it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const unsigned wq = it / (unsigned)slots;
+    const int c0 = (int)(it - wq * (unsigned)slots) << 3;
+    const unsigned win = (unsigned)w0 + wq, wy = win / (unsigned)Wo, wx = win - wy * (unsigned)Wo;
+    const int64_t pix0 = (int64_t)b * a.HW + (int64_t)(2 * wy) * a.W + 2 * wx;
+    f32x8 y[4], sv[4], mx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t pix = pix0 + (k >> 1) * a.W + (k & 1);
+      y[k] = load8(Y + pix * a.y_ld + c0);
+      sv[k] = load8(S + pix * a.s_ld + c0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t pix = pix0 + (k >> 1) * a.W + (k & 1);
+      f32x8 o, r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r.v[e] = (siluf_(y[k].v[e] * sc[c0 + e] + sh[c0 + e]) + sv[k].v[e]) * dr[c0 + e];
+        o.v[e] = r.v[e] * fg[c0 + e] + fb[c0 + e];
+        mx.v[e] = k ? fmaxf(mx.v[e], o.v[e]) : o.v[e];
+      }
+      store8(O0 + pix * a.o0_ld + c0, o);
+      if (O1) store8(O1 + pix * a.o1_ld + c0, r);
+    }
+    store8(P + ((int64_t)b * nwin + win) * a.p_ld + c0, mx);
   }
 }
 
@@ -370,6 +427,40 @@ extern "C" int sx_block_out_forward(int dtype, int B, int HW, int C, int groups,
   dim3 grid = act_grid(a);
   SX_DISPATCH_T(dtype, act_fwd_kernel, 1, grid, (hipStream_t)stream, a);
   SX_LAUNCH_CHECK("block_out_forward");
+  return SX_OK;
+}
+
+// sx_block_out_forward followed by nn.MaxPool2d(2) of `out`, in one pass (H, W even)
+extern "C" int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, int groups, float eps, const void* y2, int y_ld,
+                                         const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                                         const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                                         void* r_out, int r_ld, void* pool, int pool_ld, void* stream) {
+  SX_REQUIRE(y2 && stats && gamma && beta && s && out && pool, "sx_block_out_pool_forward: null pointer");
+  if (H < 2 || W < 2 || (H & 1) || (W & 1) || pool_ld % 8) {
+    set_error("sx_block_out_pool_forward: needs even H, W and pool_ld %% 8 == 0 (H=%d W=%d)", H, W);
+    return SX_ERR_UNSUPPORTED;
+  }
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Y = y2; a.y_ld = y_ld; a.S = s; a.s_ld = s_ld; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.gf = film_g; a.bf = film_b; a.drop = drop; a.out0 = out; a.o0_ld = out_ld; a.out1 = r_out; a.o1_ld = r_ld;
+  a.B = B; a.HW = H * W; a.C = C; a.G = groups; a.eps = eps; a.W = W; a.pool = pool; a.p_ld = pool_ld;
+  SX_TRY(act_check(a, "sx_block_out_pool_forward"));
+  // chunks of windows: the grid rule sees a quarter of the pixels, each item being four of them
+  ActArgs g = a;
+  g.HW = a.HW >> 2;
+  dim3 grid = act_grid(g);
+  a.pix_per_block = g.pix_per_block;
+  hipStream_t st = (hipStream_t)stream;
+  const bool small_c = C <= 256;
+  if (dtype == SX_BF16) {
+    if (small_c) hipLaunchKernelGGL((act_fwd_pool_kernel<bf16, 256>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((act_fwd_pool_kernel<bf16, MAXC>), grid, dim3(256), 0, st, a);
+  } else {
+    if (small_c) hipLaunchKernelGGL((act_fwd_pool_kernel<float, 256>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((act_fwd_pool_kernel<float, MAXC>), grid, dim3(256), 0, st, a);
+  }
+  SX_LAUNCH_CHECK("block_out_pool_forward");
   return SX_OK;
 }
 

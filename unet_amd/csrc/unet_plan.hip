@@ -335,7 +335,7 @@ struct WgQueue {
 
 // ---------------------------------------------------------------- one DoubleConv block
 static int block_forward(const Plan& p, int k, const float* const* params, const void* wpack, void* ws, bool film,
-                         const float* drop, hipStream_t st) {
+                         const float* drop, hipStream_t st, void* pool = nullptr, int pool_ld = 0, bool* pooled = nullptr) {
   const BlockBuf& b = p.blk[k];
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
@@ -359,6 +359,13 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
                          at(ws, b.Y2), b.C, b.H, b.W, 0, (float*)at(ws, b.st2), b.G, st));
   SX_TRY(stream_after(side, ss, st));
   const bool keep_r = film || drop;
+  if (pool && !(b.H & 1) && !(b.W & 1)) {      // encoder block: its max-pooled output in the same pass
+    *pooled = true;
+    return sx_block_out_pool_forward(dt, B, b.H, b.W, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
+                                     at(ws, b.S), b.C, film ? (const float*)at(ws, b.gf) : nullptr,
+                                     film ? (const float*)at(ws, b.bf) : nullptr, drop, at(ws, b.O), b.o_ld,
+                                     keep_r ? at(ws, b.R) : nullptr, b.C, pool, pool_ld, st);
+  }
   SX_TRY(sx_block_out_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2, at(ws, b.S), b.C,
                               film ? (const float*)at(ws, b.gf) : nullptr, film ? (const float*)at(ws, b.bf) : nullptr, drop,
                               at(ws, b.O), b.o_ld, keep_r ? at(ws, b.R) : nullptr, b.C, st));
@@ -522,8 +529,9 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
   // decoder's too) is evaluated here in one launch and sx_unet_decode launches none
   if (film) SX_TRY(film_run_forward(p, 0, d->use_film == 2 ? 2 * D + 1 : D + 1, params, ws, film_params, st));
   for (int k = 0; k <= D; ++k) {
-    SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st));
-    if (k < D)
+    bool pooled = false;
+    SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st, k < D ? at(ws, p.Pool[k]) : nullptr, k < D ? p.C[k] : 0, &pooled));
+    if (k < D && !pooled)
       SX_TRY(sx_maxpool2_forward(dt, B, p.H[k], p.W[k], p.C[k], at(ws, p.blk[k].O), 2 * p.C[k], at(ws, p.Pool[k]), p.C[k], stream));
   }
   return SX_OK;
