@@ -56,7 +56,11 @@ const char* sx_last_error(void);
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Replaces nothing in the reference (ATen consumes (Cout,Cin,kh,kw) directly);
  * the MFMA kernels want K-contiguous, zero-padded tiles in the activation dtype:
- *   packed[tap][CoutPad][CinPad], CoutPad = roundup(Cout,16), CinPad = roundup(Cin, 64B/sizeof(T)).
+ *   fp32: packed[tap][CoutPad][CinPad], CoutPad = roundup(Cout,16), CinPad = roundup(Cin, 16);
+ *   bf16: the same elements (CinPad = roundup(Cin, 32)) in 1 KB units of 16 rows x 32 k, unit order
+ *         [row/16][k/32][tap], 16-byte group (row, 8 k) at lane ((k%32)/8)*16 + row%16 inside a unit: each unit is one
+ *         contiguous wave load in MFMA A-operand order (conv_common.h: wpack_off_bf16).  The layout is private to the
+ *         library: treat a packed tensor as opaque.
  * `transpose_flip` != 0 builds the data-gradient operand of a 3x3/1x1 conv instead
  * (roles of Cin/Cout swapped, taps reversed).
  * sx_packed_weight_elems() returns the element count of the packed tensor.

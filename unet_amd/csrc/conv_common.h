@@ -6,6 +6,15 @@ namespace sx {
 
 static constexpr int ROWB = 96;   // LDS bytes per staged row (64 payload + 32 pad)
 
+// bf16 packed-weight layout.  Units of 16 rows x 32 k (1 KB) in the order [row / 16][k / 32][tap]; inside a unit the 16-byte
+// group (row, 8 consecutive k) sits at lane g * 16 + n, g = (k % 32) / 8, n = row % 16 -- the lane that feeds it to the
+// 16x16x32 MFMA as the A operand.  A wave of conv_ws_kernel therefore fetches each (16 rows, 32 k, tap) fragment as ONE
+// contiguous 1 KB load; the [tap][row][k] form cost 16 half-line requests per fragment and the weight prologue ran at
+// 13 B/cycle/CU.  fp32 packs stay [tap][row][k].
+__host__ __device__ inline int64_t wpack_off_bf16(int ntaps, int kchunks, int tap, int row, int k) {
+  return ((((int64_t)(row >> 4) * kchunks + (k >> 5)) * ntaps + tap) << 9) + (((((k & 31) >> 3) << 4) + (row & 15)) << 3) + (k & 7);
+}
+
 struct ConvArgs {
   const void* x; const void* w; void* y; const float* bias; float* gn_stats;
   int B, H, W;
@@ -23,7 +32,8 @@ struct ConvArgs {
   // fused variants of the weights-stationary kernel (conv_ws.hip)
   const void* w2;     // packed 1x1 weights: shortcut forward (second output) / shortcut dgrad (extra centre-tap K chunks)
   void* y2; int y2_ld;
-  unsigned long long* stamps;    // diagnostic build (-DSX_WS_DBG=1) only: per-block s_memtime stamps
+  unsigned long long* stamps;
+  int kc0;            // first 32-wide K chunk of the packed weights this launch covers (K slices, see KRow)    // diagnostic build (-DSX_WS_DBG=1) only: per-block s_memtime stamps
   float* ch_sum; int ch_sum_n;   // optional: ch_sum[c] += sum over all output pixels of y[..., c], c < ch_sum_n (atomics)
 };
 

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int r = p >> 2, q = p & 3;
       const int tap = r / BMC, row = r - tap * BMC;
       Vec v = {};
-      if (cb + row < a.RTot)
-        v = *reinterpret_cast<const Vec*>(wg + ((int64_t)tap * a.RTot + cb + row) * a.KPad + kc + q * EPL);
+      if (cb + row < a.RTot) {
+        if constexpr (sizeof(T) == 2) v = *reinterpret_cast<const Vec*>(wg + wpack_off_bf16(a.ntaps, a.KPad >> 5, tap, cb + row, kc + q * EPL));
+        else v = *reinterpret_cast<const Vec*>(wg + ((int64_t)tap * a.RTot + cb + row) * a.KPad + kc + q * EPL);
+      }
       *reinterpret_cast<Vec*>(sm_w + r * ROWB + q * 16) = v;
     }
     __syncthreads();
@@ -225,7 +227,8 @@ __global__ void pack_weight_kernel(PackArgs A) {
     } else {                             // SX_CONVT_BWD: rows = ci, k = co, taps = 4
       if (row < Cin && k < Cout) v = w[((int64_t)row * Cout + k) * 4 + tap];
     }
-    out[idx] = from_f32<T>(v);
+    if constexpr (sizeof(T) == 2) out[wpack_off_bf16((int)(D.total / ((int64_t)RTot * KPad)), KPad >> 5, tap, row, k)] = from_f32<T>(v);
+    else out[idx] = from_f32<T>(v);
   }
 }
 
@@ -273,7 +276,8 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
       if (co < D.RTot_f && ci < D.KPad_f) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[hi][(lo8 + i) * NT + tap];
-        store8(of + ((int64_t)tap * D.RTot_f + co) * D.KPad_f + ci, v);
+        if constexpr (sizeof(T) == 2) store8(of + wpack_off_bf16(NT, D.KPad_f >> 5, tap, co, ci), v);
+        else store8(of + ((int64_t)tap * D.RTot_f + co) * D.KPad_f + ci, v);
       }
     }
     {   // transposed: row ci0 + hi, k = co0 + lo8 .. +7, taps reversed
@@ -281,7 +285,8 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
       if (ci < D.RTot_t && co < D.KPad_t) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[lo8 + i][hi * NT + tap];
-        store8(ot + ((int64_t)(NT - 1 - tap) * D.RTot_t + ci) * D.KPad_t + co, v);
+        if constexpr (sizeof(T) == 2) store8(ot + wpack_off_bf16(NT, D.KPad_t >> 5, NT - 1 - tap, ci, co), v);
+        else store8(ot + ((int64_t)(NT - 1 - tap) * D.RTot_t + ci) * D.KPad_t + co, v);
       }
     }
   }

@@ -86,33 +86,38 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(a.y);
 
-  const int krow = a.KRow ? a.KRow : a.KPad;
-  // ---- stationary weights: A[kc][tap][j] = W[tap][cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
+  // ---- stationary weights: A[kc][tap][j] = W[tap][cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8], one contiguous 1 KB
+  // unit of the packed layout per (j, kc, tap) (conv_common.h: wpack_off_bf16); units past the last row block read as zero
+  const int kct = (a.KRow ? a.KRow : a.KPad) >> 5;     // K chunks per packed row block
+  const int r16 = (cb >> 4) + wm * MI;                 // first 16-row block of this wave
   bf16x8 A[KCH][TAPS][MI];
 #pragma unroll
-  for (int kc = 0; kc < KCH; ++kc)
+  for (int j = 0; j < MI; ++j) {
+    const bool in = (r16 + j) * 16 < a.RTot;
+    const bf16* wj = wg + (((int64_t)(r16 + j) * kct + a.kc0) * TAPS << 9) + lane * 8;
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
+    for (int kc = 0; kc < KCH; ++kc)
 #pragma unroll
-      for (int j = 0; j < MI; ++j) {
-        const int row = cb + (wm * MI + j) * 16 + n;
+      for (int tap = 0; tap < TAPS; ++tap) {
         bf16x8 v = {};
-        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg + ((int64_t)tap * a.RTot + row) * krow + kc * 32 + g * 8);
+        if (in) v = *reinterpret_cast<const bf16x8*>(wj + ((kc * TAPS + tap) << 9));
         A[kc][tap][j] = v;
       }
+  }
   // 1x1 weights of the fused variants: A2[kc][j] = W2[cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
   bf16x8 A2[VAR == WS_PLAIN ? 1 : KCH][MI];
   if constexpr (VAR != WS_PLAIN) {
     const bf16* __restrict__ wg2 = reinterpret_cast<const bf16*>(a.w2);
 #pragma unroll
-    for (int kc = 0; kc < KCH; ++kc)
+    for (int j = 0; j < MI; ++j) {
+      const bool in = (r16 + j) * 16 < a.RTot;
 #pragma unroll
-      for (int j = 0; j < MI; ++j) {
-        const int row = cb + (wm * MI + j) * 16 + n;
+      for (int kc = 0; kc < KCH; ++kc) {
         bf16x8 v = {};
-        if (row < a.RTot) v = *reinterpret_cast<const bf16x8*>(wg2 + (int64_t)row * krow + kc * 32 + g * 8);
+        if (in) v = *reinterpret_cast<const bf16x8*>(wg2 + (((int64_t)(r16 + j) * kct + a.kc0 + kc) << 9) + lane * 8);
         A2[kc][j] = v;
       }
+    }
   }
 
   // ---- staging: piece p = tid + q*256 -> halo pixel r = p>>2 (ly, lx), 16-byte part p&3.
@@ -440,7 +445,7 @@ int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
     if (rc != 0) return rc;
     h.gn_stats = a.gn_stats;
     h.x = reinterpret_cast<const bf16*>(a.x) + 256;
-    h.w = reinterpret_cast<const bf16*>(a.w) + 256;
+    h.kc0 = 8;
     h.accumulate = 1;
     return mode == SX_CONV3 ? ws_pick_k<9, WS_PLAIN>(h, st) : ws_pick_k<1, WS_PLAIN>(h, st);
   }
