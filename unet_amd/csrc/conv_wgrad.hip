@@ -191,10 +191,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A)
   int di = 0;
   while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
   const WgReduceDesc& D = A.d[di];
-  const int bchunks = (D.Cb + 63) >> 6;
-  const int64_t nunits = (int64_t)D.ntaps * D.Ca * bchunks;
   const int64_t slab_sz = (int64_t)D.ntaps * D.CaPad * D.CbPad;
   const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  if (D.tiled) {
+    // unit = four consecutive rows of one 16x16 tile (256 contiguous bytes) x all splits; thread e: row 4q + e/4, cols (e%4)*4..+3
+    const int A16 = D.CaPad >> 4, B16 = D.CbPad >> 4;
+    const int64_t nunits = (int64_t)D.ntaps * A16 * B16 * 4;
+    for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
+      const int q = (int)(u & 3);
+      const int64_t tile = u >> 2;                              // (tap * A16 + a16) * B16 + b16
+      const int b16 = (int)(tile % B16);
+      const int64_t ta = tile / B16;
+      const int a16 = (int)(ta % A16), tap = (int)(ta / A16);
+      const float* src = D.slab + (tile << 8) + q * 64 + e * 4;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int k = sl; k < D.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
+      red[sl][e] = s;
+      __syncthreads();
+      if (sl < 4) {                      // thread (e, sl) finishes column (e%4)*4 + sl of row 4q + e/4
+        const int aa = a16 * 16 + q * 4 + (e >> 2), bb = b16 * 16 + (e & 3) * 4 + sl;
+        if (aa < D.Ca && bb < D.Cb) {
+          float t = 0.f;
+#pragma unroll
+          for (int l = 0; l < 16; ++l) t += red[l][e][sl];
+          float* dst = D.out + ((int64_t)aa * D.Cb + bb) * D.ntaps + tap;
+          *dst = D.accumulate ? (*dst + t) : t;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int bchunks = (D.Cb + 63) >> 6;
+  const int64_t nunits = (int64_t)D.ntaps * D.Ca * bchunks;
   for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
     const int bc = (int)(u % bchunks);
     const int64_t row = u / bchunks;
@@ -228,7 +257,8 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
       A.d[i] = descs[i0 + i];
-      const int64_t units = (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
+      const int64_t units = A.d[i].tiled ? (int64_t)A.d[i].ntaps * (A.d[i].CaPad >> 4) * (A.d[i].CbPad >> 4) * 4
+                                         : (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
       A.d[i].blk0 = blk;
       A.d[i].nblk = (int)std::min<int64_t>(units, 1024);
       blk += A.d[i].nblk;

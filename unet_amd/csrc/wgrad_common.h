@@ -11,6 +11,7 @@ struct WgReduceDesc {
   float* out;
   int nsplit, ntaps, Ca, Cb, CaPad, CbPad;   // Ca / Cb: channels actually written (<= padded slab extents)
   int accumulate;
+  int tiled;                                 // slab layout: 0 = [tap][a][b]; 1 = 16x16 tiles, [tap][a/16][b/16][a%16][b%16] (wgrad_ws)
   int blk0, nblk;                            // block range inside a fused launch (filled by wgrad_reduce_multi)
 };
 static constexpr int WG_MAX_REDUCE = 40;     // descriptors per fused launch (kernel-argument budget)

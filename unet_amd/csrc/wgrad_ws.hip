@@ -298,18 +298,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   }
 
   const unsigned long long t_loop = DBG ? __builtin_amdgcn_s_memtime() : 0;
-  // ---- slab[split][tap][a][b]: lane (n, g) of tile (t, j) holds b = b0 + 16*bf + 4g .. +3 of row a = a0 + 16*j + n
+  // ---- slab[split][tap][a/16][b/16][a%16][b%16]: lane (n, g) of tile (t, j) holds b = b0 + 16*bf + 4g .. +3 of row
+  // a = a0 + 16*j + n, so one store instruction of a wave fills one contiguous 1 KB tile (row-major slabs made it sixteen
+  // 64-byte pieces and the store tail ran at 15 B/cycle/CU: 9.6k cycles of a 44k-cycle launch)
   const int ntaps = TAPS;
   float* slab = a.slab + (int64_t)split * ntaps * a.CaPad * a.CbPad;
+  const int B16 = a.CbPad >> 4, A16 = a.CaPad >> 4;
 #pragma unroll
   for (int t = 0; t < ITEMS; ++t) {
     if (!it_valid[t]) continue;
-    const int bcol = b0 + it_bf[t] * 16 + 4 * g;
+    const int b16 = (b0 >> 4) + it_bf[t];
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int arow = a0 + j * 16 + n;
-      if (arow < a.CaPad && bcol < a.CbPad)
-        *reinterpret_cast<f32x4*>(slab + ((int64_t)it_tap[t] * a.CaPad + arow) * a.CbPad + bcol) = acc[t][j];
+      const int a16 = (a0 >> 4) + j;
+      if (a16 < A16 && b16 < B16)
+        *reinterpret_cast<f32x4*>(slab + ((((int64_t)it_tap[t] * A16 + a16) * B16 + b16) << 8) + n * 16 + 4 * g) = acc[t][j];
     }
   }
   if (DBG && a.stamps && tid == 0) {
@@ -448,7 +451,7 @@ int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, i
   a.stamps = getenv("SX_WG_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WG_STAMPS"), nullptr, 0) : nullptr;
   const int rc = p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st);
   if (rc != SX_OK) return rc;
-  desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad;
+  desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad; desc->tiled = 1;
   return SX_OK;
 }
 
