@@ -1,0 +1,95 @@
+"""Two ranks on ONE GPU (gloo moves the CUDA tensors; the box has a single card, RCCL needs one device per rank): the real
+TrainEngine data-parallel step -- global loss denominators, the decoder-bucket all-reduce launched between the two backward
+halves, the late bucket (FiLM generators, decoder GroupNorm affines and biases finished by the encoder half under
+SX_BWD_DEFER_FILM) -- must leave every rank with the parameters a single process gets from the un-split batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OPTS = dict(lam_w=0.5, lam_grad=0.1, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1", multiscale=1,
+            ms_weight=0.5, grad_ds=2)
+STEPS = 3
+
+
+def _engine(dtype):
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.losses import edge_weights
+    from unet_amd.synth import make_batch
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=6)
+    bt = {k: v.cuda() for k, v in make_batch(8, 16, 16, seed=3, jitter_masks=True, empty_last=True).items()}
+    w = torch.from_numpy(edge_weights(bt["mask"][0, 0].cpu().numpy()))
+    m = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    eng = TrainEngine(m, dtype=dtype, lr=1e-3, weight_decay=1e-4, clip_grad=0.5, w_map=w, loss_opts=OPTS)
+    return eng, bt
+
+
+def _run(eng, bt, sl):
+    losses, grads = [], None
+    for i in range(STEPS):
+        out = eng.train_step(bt["x"][sl], bt["y"][sl], bt["mask"][sl], bt["params"][sl], lam_grad=0.1)
+        losses.append(out[0:1].clone())
+        if i == 0:      # the arena still holds the (all-reduced) gradient the optimizer just consumed
+            torch.cuda.synchronize()
+            grads = {n: p.grad.detach().cpu().clone() for n, p in eng.model.named_parameters()}
+    torch.cuda.synchronize()
+    names = [n for n, _ in eng.model.named_parameters()]
+    return torch.cat(losses).cpu(), {n: p.detach().cpu().clone() for n, p in eng.model.named_parameters()}, names, grads
+
+
+def _worker(rank, world, port, dtype_name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from unet_amd import dist as D
+    D.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    eng, bt = _engine(getattr(torch, dtype_name))
+    assert eng.world == world
+    b0, b1 = D.shard_range(bt["x"].shape[0])
+    losses, params, _, grads = _run(eng, bt, slice(b0, b1))
+    tot = losses.cuda()
+    D.all_reduce_sum(tot)                   # per-rank shares of the global loss
+    # numpy: pickled by value (torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, tot.cpu().numpy(), {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in grads.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 3e-2)])
+def test_two_rank_engine_steps_equal_single_process(dtype_name, tol):
+    sys.path.insert(0, ROOT)
+    from helpers import rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(t), {k: torch.from_numpy(v) for k, v in pr.items()}, {k: torch.from_numpy(v) for k, v in gr.items()})
+           for r, t, pr, gr in res]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eng, bt = _engine(getattr(torch, dtype_name))
+    losses, params, names, grads = _run(eng, bt, slice(0, bt["x"].shape[0]))
+    for rank, tot, pr, gr in res:
+        assert float((tot - losses).abs().max()) < tol * float(losses.abs().max()), (rank, tot, losses)
+        for n in names:
+            # the gradient is the sharp check (AdamW's first steps move a weight by ~lr whatever the gradient's size)
+            assert rel_err(gr[n], grads[n]) < tol, (rank, n, "grad")
+            assert rel_err(pr[n], params[n]) < tol, (rank, n)
+    # both ranks hold the same parameters bit for bit (same reduced gradients, same optimizer arithmetic)
+    for n in names:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n
