@@ -123,7 +123,9 @@ int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int 
  *   sx_gn_silu_forward : out = SiLU(GN(y))
  *   sx_block_out_forward: R = (SiLU(GN(y2)) + s) * drop ; out = R * film_g + film_b ; r_out = R
  *                         (film_g/film_b/drop: fp32 [B][C] or NULL; r_out may be NULL)
- *   sx_gn_silu_backward: mode 0 through SiLU(GN(y)); mode 1 through the block output.
+ *   sx_gn_silu_backward: mode 0 through SiLU(GN(y)); mode 1 through the block output (r = the saved R);
+ *       mode 2 = mode 1 with r = the shortcut branch s of sx_block_out_forward: R is rebuilt as (SiLU(GN(y)) + s) * drop,
+ *       so the forward pass need not store it (r_out = NULL).
  *       sums: zeroed fp32 [B][C][4] = {sum dz*n_hat, sum dz, sum d_out*R, sum d_out} per (b,c)
  *       (entries 2,3 are the FiLM gamma/beta gradients); dy = gradient w.r.t. y; d_r (mode 1,
  *       optional) = d_out*film_g*drop = gradient w.r.t. the shortcut branch; dgamma/dbeta optional.

@@ -324,6 +324,15 @@ def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):
     assert rel_err(from_nhwc(dR, Cc), sr.grad) < tol
     assert rel_err(dg.cpu(), gr.grad) < tol and rel_err(db.cpu(), br.grad) < tol
     assert rel_err(sums[..., 2].cpu(), gfr.grad) < tol and rel_err(sums[..., 3].cpu(), bfr.grad) < tol
+    # mode 2: R rebuilt from the shortcut branch instead of read back
+    sums2 = torch.zeros(B, Cc, 4, dtype=torch.float32, device="cuda")
+    dy2, dR2 = torch.empty_like(out), torch.empty_like(out)
+    L.check(lib.sx_gn_silu_backward(dtype, 2, B, H * W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gmd), L.ptr(btd), L.ptr(dOd), Cc,
+                                    L.ptr(sd), Cc, L.ptr(gfd), L.ptr(drd), L.ptr(sums2), L.ptr(dy2), Cc, L.ptr(dR2), Cc, None, None,
+                                    0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel_err(sums2[..., 2].cpu(), gfr.grad) < tol and rel_err(sums2[..., 3].cpu(), bfr.grad) < tol
+    assert rel_err(from_nhwc(dy2, Cc), yr.grad) < tol and torch.equal(dR2, dR)
     # mode 0: plain SiLU(GN(y))
     yr2 = y2.clone().requires_grad_(True)
     A = F.silu(F.group_norm(yr2, G, gamma, beta, eps=1e-5))

@@ -34,6 +34,7 @@ struct ActArgs {
   float eps;
   int pix_per_block;
   int W; void* pool; int p_ld;    // fused 2x2 max-pool of out0 (act_fwd_pool_kernel)
+  int r_is_s;                     // backward mode 2: R points at the shortcut branch S, R = (silu(z) + S) * drop is recomputed
 };
 
 // per-channel GN coefficients of sample b into LDS: n_hat = y * rs[c] - mr[c]; z = n_hat * ga[c] + be[c]
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void act_fwd_pool_kernel(ActArgs a) {
 template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
   constexpr int CH = 4;
-  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX];
+  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX], drp[MODE ? CMAX : 1];
   __shared__ float red[256 * CH];
   const int b = blockIdx.y;
   gn_coeffs(a, b, rs, mr);
@@ -178,8 +179,10 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
     be[c] = a.beta[c];
     float f = 1.f;
     if (MODE) {
+      const float dr = a.drop ? a.drop[(int64_t)b * a.C + c] : 1.f;
       if (a.gf) f *= a.gf[(int64_t)b * a.C + c];
-      if (a.drop) f *= a.drop[(int64_t)b * a.C + c];
+      f *= dr;
+      drp[c] = dr;
     }
     fac[c] = f;
   }
@@ -211,10 +214,16 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
       for (int e = 0; e < CH; ++e) {
         const float nh = y[e] * rs[c0 + e] - mr[c0 + e];
         const float z = nh * ga[c0 + e] + be[c0 + e];
-        const float dz = g[e] * dsiluf_(z);
+        const float sg = sigmoidf_(z);
+        const float dz = g[e] * (sg * (1.0f + z * (1.0f - sg)));     // g * silu'(z)
         acc[0][e] += dz * nh;
         acc[1][e] += dz;
-        if (MODE) { acc[2][e] += g[e] * r[e]; acc[3][e] += g[e]; }
+        if (MODE) {
+          // mode 2: the forward pass did not store R; rebuild it from the shortcut branch (z * sg = silu(z))
+          const float rr = a.r_is_s ? (z * sg + r[e]) * drp[c0 + e] : r[e];
+          acc[2][e] += g[e] * rr;
+          acc[3][e] += g[e];
+        }
       }
     }
 #pragma unroll
@@ -472,13 +481,13 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
                                    const float* drop, float* sums, void* dy, int dy_ld, void* d_r, int dr_ld,
                                    float* dgamma, float* dbeta, int accumulate, void* stream) {
   SX_REQUIRE(y && stats && gamma && beta && d_out && sums && dy, "sx_gn_silu_backward: null pointer");
-  SX_REQUIRE(mode == 0 || (mode == 1 && r), "sx_gn_silu_backward: mode 1 needs the saved block sum R");
+  SX_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && r), "sx_gn_silu_backward: mode 1 needs the saved block sum R, mode 2 the shortcut branch S");
   ActArgs a;
   memset(&a, 0, sizeof(a));
   a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dO = d_out; a.do_ld = do_ld;
   a.R = r; a.r_ld = r_ld; a.gf = film_g; a.drop = drop; a.sums = sums; a.out0 = dy; a.o0_ld = dy_ld;
   a.out1 = d_r; a.o1_ld = dr_ld;
-  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps; a.r_is_s = mode == 2;
   SX_TRY(act_check(a, "sx_gn_silu_backward"));
   dim3 grid = act_grid(a);
   hipStream_t st = (hipStream_t)stream;

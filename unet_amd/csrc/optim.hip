@@ -6,7 +6,19 @@
 
 namespace sx {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// Block partials of sx_grad_sumsq (one copy per device; referenced by the kernels only).  The norm must come out bit-identical
+// on every data-parallel rank -- it sets the clip factor, and ranks whose clip factors differ in the last bit drift apart --
+// so the partials are summed in a fixed order by a second one-block launch instead of racing on an atomic.
+static __device__ float g_sumsq_part[256];
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int nparts, float* __restrict__ out) {
+  float v[1] = {(int)threadIdx.x < nparts ? g_sumsq_part[threadIdx.x] : 0.f};
+  __shared__ float red[4];
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) out[0] += v[0];
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n) {
   float v[1] = {0.f};
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -16,7 +28,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[n4 * 4 + threadIdx.x]; v[0] += x * x; }
   __shared__ float red[4];
   block_sum<1>(v, red);
-  if (threadIdx.x == 0) atomicAdd(out, v[0]);
+  if (threadIdx.x == 0) g_sumsq_part[blockIdx.x] = v[0];
 }
 
 struct AdamArgs {
@@ -66,15 +78,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 using namespace sx;
 
-// out[0] += sum g^2 (caller zeroes out)
+// out[0] += sum g^2 (caller zeroes out).  Deterministic: fixed grid, fixed-order sums.  Calls that overlap on one device
+// (different streams) race on the partials scratch.
 extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
   SX_REQUIRE(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq: bad arguments");
   if (n == 0) return SX_OK;
-  // every block ends in one atomic on the SAME address (~13 ns each, serialised in the L2): 1024 blocks spent 13 of the
-  // kernel's 16 us there; 256 blocks read the same bytes with a quarter of the queue
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 256));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n);
   SX_LAUNCH_CHECK("grad_sumsq");
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, blocks, out);
+  SX_LAUNCH_CHECK("grad_sumsq_final");
   return SX_OK;
 }
 

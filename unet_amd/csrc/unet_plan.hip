@@ -127,7 +127,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     }
     b.C = p.C[l]; b.H = p.H[l]; b.W = p.W[l];
     b.G = std::min(d.groups_gn, b.C);
-    b.Y1 = act(l, b.C); b.A1 = act(l, b.C); b.Y2 = act(l, b.C); b.S = act(l, b.C); b.R = act(l, b.C);
+    b.Y1 = act(l, b.C); b.A1 = act(l, b.C); b.Y2 = act(l, b.C); b.S = act(l, b.C);
     if (k < D) { b.O = p.cat[l] + (int64_t)b.C * p.esz; b.o_ld = 2 * b.C; }
     else { b.O = act(l, b.C); b.o_ld = b.C; }
     b.dO = act(l, b.C); b.dY = act(l, b.C); b.dA1 = act(l, b.C);
@@ -364,11 +364,11 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
     return sx_block_out_pool_forward(dt, B, b.H, b.W, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                                      at(ws, b.S), b.C, film ? (const float*)at(ws, b.gf) : nullptr,
                                      film ? (const float*)at(ws, b.bf) : nullptr, drop, at(ws, b.O), b.o_ld,
-                                     keep_r ? at(ws, b.R) : nullptr, b.C, pool, pool_ld, st);
+                                     nullptr, 0, pool, pool_ld, st);
   }
   SX_TRY(sx_block_out_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2, at(ws, b.S), b.C,
                               film ? (const float*)at(ws, b.gf) : nullptr, film ? (const float*)at(ws, b.bf) : nullptr, drop,
-                              at(ws, b.O), b.o_ld, keep_r ? at(ws, b.R) : nullptr, b.C, st));
+                              at(ws, b.O), b.o_ld, nullptr, 0, st));
   return SX_OK;
 }
 
@@ -383,10 +383,12 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
   const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
   const bool keep_r = film || drop;
-  const void* Rsrc = keep_r ? at(ws, b.R) : at(ws, b.O);
+  // R = (SiLU(GN(y2)) + S) * drop is not stored by the forward pass: with FiLM or dropout the reduction rebuilds it from
+  // the shortcut branch S (mode 2; one tensor write per block saved), without them R is the block output itself
+  const void* Rsrc = keep_r ? at(ws, b.S) : at(ws, b.O);
   const int r_ld = keep_r ? b.C : b.o_ld;
   // through FiLM / dropout / residual / SiLU / GN2
-  SX_TRY(sx_gn_silu_backward(dt, 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
+  SX_TRY(sx_gn_silu_backward(dt, keep_r ? 2 : 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                              at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
                              (float*)at(ws, b.sums2), at(ws, b.dY), b.C, at(ws, b.dR), 2 * b.C,
                              nullptr, nullptr, acc, st));
