@@ -34,7 +34,6 @@ struct ActArgs {
   float eps;
   int pix_per_block;
   int W; void* pool; int p_ld;    // fused 2x2 max-pool of out0 (act_fwd_pool_kernel)
-  int r_is_s;                     // backward mode 2: R points at the shortcut branch S, R = (silu(z) + S) * drop is recomputed
 };
 
 // per-channel GN coefficients of sample b into LDS: n_hat = y * rs[c] - mr[c]; z = n_hat * ga[c] + be[c]
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256) void act_fwd_pool_kernel(ActArgs a) {
 template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
   constexpr int CH = 4;
-  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX], drp[MODE ? CMAX : 1];
+  __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX], drp[MODE == 2 ? CMAX : 1];
   __shared__ float red[256 * CH];
   const int b = blockIdx.y;
   gn_coeffs(a, b, rs, mr);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
       const float dr = a.drop ? a.drop[(int64_t)b * a.C + c] : 1.f;
       if (a.gf) f *= a.gf[(int64_t)b * a.C + c];
       f *= dr;
-      drp[c] = dr;
+      if (MODE == 2) drp[c] = dr;
     }
     fac[c] = f;
   }
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
         acc[1][e] += dz;
         if (MODE) {
           // mode 2: the forward pass did not store R; rebuild it from the shortcut branch (z * sg = silu(z))
-          const float rr = a.r_is_s ? (z * sg + r[e]) * drp[c0 + e] : r[e];
+          const float rr = MODE == 2 ? (z * sg + r[e]) * drp[c0 + e] : r[e];
           acc[2][e] += g[e] * rr;
           acc[3][e] += g[e];
         }
@@ -487,13 +486,14 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dO = d_out; a.do_ld = do_ld;
   a.R = r; a.r_ld = r_ld; a.gf = film_g; a.drop = drop; a.sums = sums; a.out0 = dy; a.o0_ld = dy_ld;
   a.out1 = d_r; a.o1_ld = dr_ld;
-  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps; a.r_is_s = mode == 2;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
   SX_TRY(act_check(a, "sx_gn_silu_backward"));
   dim3 grid = act_grid(a);
   hipStream_t st = (hipStream_t)stream;
   // the block-output pass (four sums, three tensors) pays more per block for its combine: half as many blocks
   dim3 grid_r = mode ? act_grid(a, 1024) : grid;
-  if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid_r, st, a); }
+  if (mode == 2) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 2, grid_r, st, a); }
+  else if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid_r, st, a); }
   else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid_r, st, a); }
   grid = act_grid(a);
   SX_LAUNCH_CHECK("gn_bwd_reduce");
