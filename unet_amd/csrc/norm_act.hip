@@ -170,7 +170,7 @@ template <typename T, int MODE, int CMAX>
 __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
   constexpr int CH = 4;
   __shared__ float rs[CMAX], mr[CMAX], ga[CMAX], be[CMAX], fac[CMAX], drp[MODE == 2 ? CMAX : 1];
-  __shared__ float red[256 * CH];
+  __shared__ float red[MODE ? 4 : 2][256 * CH];
   const int b = blockIdx.y;
   gn_coeffs(a, b, rs, mr);
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
@@ -228,34 +228,39 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) { acc[0][e] *= fac[c0 + e]; acc[1][e] *= fac[c0 + e]; }
   }
-  // reduce over the pixel lanes that share a slot: red = [lane][C] floats
+  // reduce over the pixel lanes that share a slot: red[k] = [lane][C] floats.  All NS sums go through LDS together (three
+  // barriers in all; one sum at a time was four barriers per sum, and this tail is what a small launch consists of)
   const bool fold = a.C <= NT && NT % a.C == 0;   // then element j*NT + t belongs to channel t % C for every j
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int e = 0; e < CH; ++e) red[k][threadIdx.x * CH + e] = acc[k][e];
+  __syncthreads();
+  if (fold) {
+    float s[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      s[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s[k] += red[k][j * NT + threadIdx.x];
+    }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = acc[k][e];
+    for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = s[k];
     __syncthreads();
-    if (fold) {
-      // every thread: CH fixed-stride reads (pipelined), then NT / C partials per channel
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < CH; ++j) s += red[j * NT + threadIdx.x];
-      __syncthreads();
-      red[threadIdx.x] = s;
-      __syncthreads();
-      if ((int)threadIdx.x < a.C) {
-        float t = 0.f;
-#pragma unroll 8
-        for (int q = threadIdx.x; q < NT; q += a.C) t += red[q];
-        atomicAdd(a.sums + ((int64_t)b * a.C + threadIdx.x) * 4 + k, t);
-      }
-    } else {
-      for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-        float s = 0.f;
-        for (int l = 0; l < lanes; ++l) s += red[l * a.C + c];
-        atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, s);
-      }
+    const int per = NT / a.C;                     // partials per channel
+    for (int o = threadIdx.x; o < NS * a.C; o += NT) {
+      const int k = o / a.C, c = o - k * a.C;
+      float t = 0.f;
+      for (int q = 0; q < per; ++q) t += red[k][c + q * a.C];
+      atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, t);
+    }
+  } else {
+    for (int o = threadIdx.x; o < NS * a.C; o += NT) {
+      const int k = o / a.C, c = o - k * a.C;
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += red[k][l * a.C + c];
+      atomicAdd(a.sums + ((int64_t)b * a.C + c) * 4 + k, t);
     }
   }
 }
