@@ -139,16 +139,27 @@ class TrainEngine:
             masks.append(torch.bernoulli(torch.full((sess.B, c), keep, device=self.device, dtype=torch.float32)) / keep)
         return masks, L.ptr_table(masks)
 
-    def _loss(self, sess, bufs, y, mask, lam_grad, want_grad, grad_scale):
+    def _loss_begin(self, sess, bufs, mask, lam_grad):
+        """Phase 1 of the loss: the denominators depend on the masks only, so they are formed -- and under DP all-reduced,
+        asynchronously -- BEFORE the network's forward pass; the collective's latency hides behind it."""
+        o = self.loss_opts
+        B, H, W, Cc = sess.B, sess.H, sess.W, self.cfg["out_ch"]
+        m = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.float().contiguous()
+        loss_prepare(bufs, B, Cc, H, W, m, self.w_map, o["multiscale"], o["grad_ds"], float(lam_grad))
+        px_local, handle = None, None
+        if self.world > 1:
+            px_local = bufs.den[0].clone()
+            handle = sxdist.all_reduce_sum(bufs.den, async_op=True)        # batch-global denominators (SURVEY 8e)
+        return m, px_local, handle
+
+    def _loss_end(self, sess, bufs, y, begun, lam_grad, want_grad, grad_scale):
         o = dict(self.loss_opts)
         o["lam_grad"] = float(lam_grad)
+        m, px_local, handle = begun
         B, H, W, Cc = sess.B, sess.H, sess.W, self.cfg["out_ch"]
         tgt = y if (y.dtype == torch.float32 and y.is_contiguous()) else y.float().contiguous()
-        m = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.float().contiguous()
-        loss_prepare(bufs, B, Cc, H, W, m, self.w_map, o["multiscale"], o["grad_ds"], o["lam_grad"])
-        px_local = bufs.den[0].clone() if self.world > 1 else None
-        if self.world > 1:
-            sxdist.all_reduce_sum(bufs.den)            # batch-global denominators
+        if handle is not None:
+            handle.wait()
         pred = sess.view(L.SX_T_PRED)
         dpred = sess.view(L.SX_T_DPRED) if want_grad else None
         ld = pred.stride(3)
@@ -170,12 +181,13 @@ class TrainEngine:
         x, fp = self._inputs(x, params)
         B, _, H, W = x.shape
         sess, bufs = self._session(B, H, W, fp is not None)
+        lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
+        begun = self._loss_begin(sess, bufs, mask, lg)
         sess.pack_weights()
         masks, drop_table = self._drop_table(sess)
         sess.encode(x, fp)
         sess.decode(fp, drop_table)
-        lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
-        out = self._loss(sess, bufs, y, mask, lg, True, 1.0 / max(int(grad_accum_steps), 1))
+        out = self._loss_end(sess, bufs, y, begun, lg, True, 1.0 / max(int(grad_accum_steps), 1))
         flags = L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0)
         sess.decode_backward(fp, drop_table, flags | L.SX_BWD_ZERO_DPARAMS)
         h_dec = None
@@ -221,11 +233,12 @@ class TrainEngine:
         x, fp = self._inputs(x, params)
         B, _, H, W = x.shape
         sess, bufs = self._session(B, H, W, fp is not None)
+        lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
+        begun = self._loss_begin(sess, bufs, mask, lg)
         sess.pack_weights()
         sess.encode(x, fp)
         sess.decode(fp, None)
-        lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
-        out = self._loss(sess, bufs, y, mask, lg, False, 1.0)
+        out = self._loss_end(sess, bufs, y, begun, lg, False, 1.0)
         if norm is not None and err_acc is not None:
             from .data import norm_table
             pred = sess.view(L.SX_T_PRED)
