@@ -159,3 +159,27 @@ def test_load_checkpoint_depth3_round_trip(tmp_path):
     np.testing.assert_allclose(te, out[0], rtol=1e-4, atol=1e-5 * np.abs(out[0]).max())
     with pytest.raises(ValueError):
         predict_fields(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy(), Rn=np.zeros((3, 3)), Zn=np.zeros((3, 3)))
+
+
+def test_engine_dp_code_path_single_process_equals_plain_step():
+    """world > 1 makes the engine split the encoder half's backward (SX_BWD_ONLY_BOTTLENECK / SX_BWD_AFTER_BOTTLENECK) and
+    issue its collectives; with no process group they are no-ops, so the gradients must equal the one-call path's."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.synth import make_batch
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=9)
+    bt = {k: v.cuda() for k, v in make_batch(4, 16, 16, seed=4, jitter_masks=True).items()}
+    grads = []
+    for world in (1, 2):
+        m = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+        m.load_state_dict(sd)
+        eng = TrainEngine(m.cuda().train(), dtype=torch.float32, lr=1e-3, clip_grad=1.0)
+        eng.world = world
+        assert eng.n_dec < eng.n_bot < eng.flat_g.numel()
+        eng.train_step(bt["x"], bt["y"], bt["mask"], bt["params"], lam_grad=0.1)
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
+    for k in grads[0]:
+        assert rel_err(grads[1][k], grads[0][k]) < 1e-5, k

@@ -644,7 +644,13 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
   const bool film = d->use_film != 0;
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
-  {
+  // SX_BWD_ONLY_BOTTLENECK / SX_BWD_AFTER_BOTTLENECK split this call in two so that a data-parallel caller can start the
+  // all-reduce of the bottleneck's convolution weights (40 % of all parameters) while the encoder levels are still being
+  // back-propagated.  The first part ends with the bottleneck's slab reduction; its GroupNorm sums stay in the workspace
+  // and are finished, with everything else, by the second part.
+  const bool only_bot = (flags & SX_BWD_ONLY_BOTTLENECK) != 0, after_bot = (flags & SX_BWD_AFTER_BOTTLENECK) != 0;
+  SX_REQUIRE(!(only_bot && after_bot), "sx_unet_encode_backward: ONLY_BOTTLENECK and AFTER_BOTTLENECK are two separate calls");
+  if (!after_bot) {
     const int64_t s0 = p.blk[0].sums1, s1 = p.blk[D + 1].sums1;
     hipError_t e = hipSuccess;
     if (!(flags & SX_BWD_DEFER_FILM)) e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);   // else: cleared by the decoder half
@@ -656,7 +662,17 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
   }
   WgQueue wq(p, ws, (flags & SX_BWD_ACCUMULATE) ? 1 : 0, st);
   // bottleneck: d_out already in blk[D].dO ; skips' gradients in dcat[l] upper halves
-  SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, wq, st));
+  if (!after_bot) SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, wq, st));
+  if (only_bot) {
+    wq.gn.clear();
+    SX_TRY(wq.flush());
+    return stream_after(wq.side, wq.st, st);
+  }
+  if (after_bot && wg) {
+    const BlockBuf& b = p.blk[D];
+    wq.add_gn((const float*)at(ws, b.sums2), grads[b.pidx + 4], grads[b.pidx + 5], b.C);
+    wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
+  }
   for (int l = D - 1; l >= 0; --l) {
     const BlockBuf& b = p.blk[l];
     const BlockBuf& nxt = p.blk[l + 1];   // its dX is d(pool_l)

@@ -78,10 +78,16 @@ class TrainEngine:
         def late(n):       # decoder-half parameters whose gradients SX_BWD_DEFER_FILM finishes in the encoder half
             return (n.startswith("film_dec.") or (n.startswith("decoders.") and (".net.1." in n or ".net.4." in n))
                     or n == "out.bias" or (n.startswith("up_convs.") and n.endswith(".bias")))
+        # third bucket boundary: the bottleneck's convolution weights (40 % of the parameters) are complete after the first
+        # part of the encoder half (SX_BWD_ONLY_BOTTLENECK); their all-reduce overlaps the encoder levels' backward
+        def botw(n):
+            return n in ("bot.net.0.weight", "bot.net.3.weight", "bot.shortcut.weight")
         dec = [names[i] for i in model._dec_idx if not late(names[i])]
-        enc = [names[i] for i in model._dec_idx if late(names[i])] + [names[i] for i in model._enc_idx]
-        self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + enc)
-        self.n_dec = self.slots[enc[0]][0] if enc else self.flat_p.numel()
+        bot = [names[i] for i in model._enc_idx if botw(names[i])]
+        enc = [names[i] for i in model._dec_idx if late(names[i])] + [names[i] for i in model._enc_idx if not botw(names[i])]
+        self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + bot + enc)
+        self.n_dec = self.slots[(bot + enc)[0]][0] if (bot + enc) else self.flat_p.numel()
+        self.n_bot = self.slots[enc[0]][0] if enc else self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_count = 0
@@ -194,12 +200,20 @@ class TrainEngine:
         closing = step_now and (self.accum + 1 >= max(int(grad_accum_steps), 1))
         if self.world > 1 and closing:
             h_dec = sxdist.all_reduce_sum(self.flat_g[:self.n_dec], async_op=True)
-        sess.encode_backward(fp, flags)
+        h_bot = None
+        if self.world > 1 and closing and self.n_bot > self.n_dec:
+            sess.encode_backward(fp, flags | L.SX_BWD_ONLY_BOTTLENECK)
+            h_bot = sxdist.all_reduce_sum(self.flat_g[self.n_dec:self.n_bot], async_op=True)
+            sess.encode_backward(fp, flags | L.SX_BWD_AFTER_BOTTLENECK)
+        else:
+            sess.encode_backward(fp, flags)
         self.accum += 1
         if closing:
             if self.world > 1:
-                h_enc = sxdist.all_reduce_sum(self.flat_g[self.n_dec:], async_op=True)
+                h_enc = sxdist.all_reduce_sum(self.flat_g[(self.n_bot if h_bot is not None else self.n_dec):], async_op=True)
                 h_dec.wait()
+                if h_bot is not None:
+                    h_bot.wait()
                 h_enc.wait()
             self.optimizer_step(lr)
         return out
