@@ -77,7 +77,11 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   // contiguous tile range per block: neighbouring tiles share halo rows in L2 and belong to the same sample,
   // so the GroupNorm partial sums are flushed once per (block, sample) instead of once per tile
   const int tpb = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t_begin = blockIdx.x * tpb;
+  // blocks are dealt to the 8 XCDs round-robin: give each XCD a contiguous eighth of the tile space, so that neighbouring
+  // tile ranges (shared halo rows, same sample) meet in one L2
+  int bx = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);
+  const int t_begin = bx * tpb;
   const int t_end = min(ntiles, t_begin + tpb);
   if (t_begin >= t_end) return;
   const int nst = (t_end - t_begin) * KTOT;
