@@ -196,13 +196,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A)
   if (D.tiled) {
     // unit = four consecutive rows of one 16x16 tile (256 contiguous bytes) x all splits; thread e: row 4q + e/4, cols (e%4)*4..+3
     const int A16 = D.CaPad >> 4, B16 = D.CbPad >> 4;
-    const int64_t nunits = (int64_t)D.ntaps * A16 * B16 * 4;
+    const int a16_n = D.a16_n ? D.a16_n : A16, tap_n = D.a16_n ? D.tap_n : D.ntaps;
+    const int64_t nunits = (int64_t)tap_n * a16_n * B16 * 4;
     for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
       const int q = (int)(u & 3);
-      const int64_t tile = u >> 2;                              // (tap * A16 + a16) * B16 + b16
-      const int b16 = (int)(tile % B16);
-      const int64_t ta = tile / B16;
-      const int a16 = (int)(ta % A16), tap = (int)(ta / A16);
+      const int64_t tl = u >> 2;                                // (tap * a16_n + a16) * B16 + b16, local to this descriptor
+      const int b16 = (int)(tl % B16);
+      const int64_t ta = tl / B16;
+      const int a16 = (int)(ta % a16_n), tap = (int)(ta / a16_n);
+      const int64_t tile = ((int64_t)(D.tap_lo + tap) * A16 + D.a16_lo + a16) * B16 + b16;
       const float* src = D.slab + (tile << 8) + q * 64 + e * 4;
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       for (int k = sl; k < D.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A)
           float t = 0.f;
 #pragma unroll
           for (int l = 0; l < 16; ++l) t += red[l][e][sl];
-          float* dst = D.out + ((int64_t)aa * D.Cb + bb) * D.ntaps + tap;
+          float* dst = D.out + ((int64_t)aa * D.Cb + bb) * tap_n + tap;
           *dst = D.accumulate ? (*dst + t) : t;
         }
       }
@@ -257,7 +259,8 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
       A.d[i] = descs[i0 + i];
-      const int64_t units = A.d[i].tiled ? (int64_t)A.d[i].ntaps * (A.d[i].CaPad >> 4) * (A.d[i].CbPad >> 4) * 4
+      const int64_t units = A.d[i].tiled ? (int64_t)(A.d[i].a16_n ? A.d[i].tap_n : A.d[i].ntaps) *
+                                               (A.d[i].a16_n ? A.d[i].a16_n : (A.d[i].CaPad >> 4)) * (A.d[i].CbPad >> 4) * 4
                                          : (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
       A.d[i].blk0 = blk;
       A.d[i].nblk = (int)std::min<int64_t>(units, 1024);

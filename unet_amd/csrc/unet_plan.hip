@@ -163,6 +163,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     wneed(SX_CONV3, b.H, b.W, b.C, b.C);
     wneed(SX_CONV3, b.H, b.W, b.C, b.Cin);
     wneed(SX_CONV1, b.H, b.W, b.C, b.Cin);
+    if (2 * b.C == 64 && b.Cin >= 64) wneed(SX_CONV3, b.H, b.W, 2 * b.C, b.Cin);     // fused conv1 + shortcut launch (WgQueue::add_dual)
   }
   for (int j = 0; j < D; ++j) {
     const int l = D - 1 - j;
@@ -322,6 +323,29 @@ struct WgQueue {
     used = 0;
     return SX_OK;
   }
+  // conv1 (3x3) and the 1x1 shortcut of a 32-channel DoubleConv in ONE launch: P = the [dY1 | dR] buffer, 64 channels = one
+  // full 128-byte line per pixel (each half on its own is half-line reads of the same lines), the shortcut rows multiply the
+  // centre tap only; two descriptors reduce the two row ranges of the slab.  Returns 1 when the shape is not covered.
+  int add_dual(int H, int W, int C, int Cb, int Cb_out, const void* P, const void* Q, int q_ld, float* dw3, float* dw1) {
+    if (dtype != SX_BF16 || 2 * C != 64 || Cb < 64) return 1;
+    const int64_t bytes = wgrad_ws_slab_bytes(SX_CONV3, B, H, W, 2 * C, Cb);
+    if (bytes <= 0) return 1;
+    const int64_t need = (int64_t)align_up((size_t)bytes, 256);
+    if (need > cap) return 1;
+    if (used + need > cap) SX_TRY(flush());
+    WgReduceDesc d;
+    memset(&d, 0, sizeof(d));
+    const int rc = wgrad_ws_try(SX_CONV3, B, H, W, 2 * C, Cb, P, 2 * C, Q, q_ld, H, W, (float*)(base + used), &d, st, 1);
+    if (rc != 0) return rc;
+    d.Ca = C; d.Cb = Cb_out; d.accumulate = acc;
+    WgReduceDesc d3 = d, d1 = d;
+    d3.out = dw3; d3.a16_lo = 0; d3.a16_n = C / 16; d3.tap_lo = 0; d3.tap_n = 9;
+    d1.out = dw1; d1.a16_lo = C / 16; d1.a16_n = C / 16; d1.tap_lo = 4; d1.tap_n = 1;
+    pending.push_back(d3);
+    pending.push_back(d1);
+    used += need;
+    return SX_OK;
+  }
   int add(int mode, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out, const void* P, int p_ld, const void* Q, int q_ld,
           int Hq, int Wq, float* dw) {
     const int64_t need = (int64_t)align_up((size_t)sx_conv_wgrad_workspace_bytes(mode, B, H, W, Ca, Cb), 256);
@@ -413,8 +437,12 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
   if (wg) {
     SX_TRY(wq.fork());
-    SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY1), 2 * b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
-    SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, dr_ld, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
+    const int rc = wq.add_dual(b.H, b.W, b.C, b.Cin, b.Cin_real, at(ws, b.dY1), at(ws, b.in), b.in_ld, grads[b.pidx + 0], grads[b.pidx + 6]);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, at(ws, b.dY1), 2 * b.C, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 0]));
+      SX_TRY(wq.add(SX_CONV1, b.H, b.W, b.C, b.Cin, b.C, b.Cin_real, dR, dr_ld, at(ws, b.in), b.in_ld, b.H, b.W, grads[b.pidx + 6]));
+    }
   }
   if (need_dx) {
     // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer

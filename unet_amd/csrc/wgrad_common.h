@@ -12,6 +12,7 @@ struct WgReduceDesc {
   int nsplit, ntaps, Ca, Cb, CaPad, CbPad;   // Ca / Cb: channels actually written (<= padded slab extents)
   int accumulate;
   int tiled;                                 // slab layout: 0 = [tap][a][b]; 1 = 16x16 tiles, [tap][a/16][b/16][a%16][b%16] (wgrad_ws)
+  int a16_lo, a16_n, tap_lo, tap_n;          // tiled slabs: the row blocks / taps this descriptor reduces (a16_n = 0: all of them)
   int blk0, nblk;                            // block range inside a fused launch (filled by wgrad_reduce_multi)
 };
 static constexpr int WG_MAX_REDUCE = 40;     // descriptors per fused launch (kernel-argument budget)
@@ -27,6 +28,9 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
 // Persistent bf16 tier.  slab bytes it needs (0 = shape not covered) / launch (0 = launched, 1 = not covered, <0 error).
 int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb);
 int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                 float* slab, WgReduceDesc* desc, hipStream_t st);
+                 float* slab, WgReduceDesc* desc, hipStream_t st, int dual = 0);
+// dual: P = [dY1 | dR] of a DoubleConv with 2 * C == 64 channels (one a tile) and >= 64 input channels; rows C .. 2C-1 of the
+// slab are valid for the centre tap only (the 1x1 shortcut's weight gradient).  The caller reduces the two row ranges with
+// two descriptors (a16_lo / a16_n / tap_lo / tap_n).
 
 }  // namespace sx

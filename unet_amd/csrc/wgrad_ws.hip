@@ -94,7 +94,7 @@ struct WgTilePos {
 // the block's a (P) / b (Q) range.  TWL: log2 of the tile width (16x8 or 8x16 pixels).
 static constexpr bool DBG = false;  // SX_WG_DBG ablation switches (bit 0: no MFMA loop, bit 1: no operand traffic)
 
-template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF>
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF, bool DUAL = false>
 __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr bool CT = TAPS == 4;                       // transposed conv: four parity sub-images of Q, no halo
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   bool it_valid[ITEMS];
 #pragma unroll
   for (int t = 0; t < ITEMS; ++t) {
-    const int it = wid * ITEMS + t;
+    // DUAL (NBF == 4): item t of every wave is tap t (bf = wave), so "is this the centre tap" is known at compile time
+    const int it = DUAL ? t * 4 + wid : wid * ITEMS + t;
     it_valid[t] = it < NIT;
     const int itc = it_valid[t] ? it : 0;
     const int tl = itc / NBF, bf = itc - tl * NBF;
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
         if constexpr (ks < 3) wg_issue_tr<(ks + 1) * YS * QPITCH * QB>(Bq[nxt][t], aQ[t][0], aQ[t][1]);
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[cur][t].v(), Af[cur][j].v(), acc[t][j], 0, 0, 0);
+          if (!DUAL || j < MI / 2 || t == 4)      // DUAL: fragments 2, 3 of P are the shortcut's dR -- centre tap only (static)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[cur][t].v(), Af[cur][j].v(), acc[t][j], 0, 0, 0);
       }
     });
   }
@@ -386,7 +388,7 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
   return p;
 }
 
-template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL>
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, bool DUAL = false>
 static int launch_wgws(const WgWsArgs& a, hipStream_t st) {
   constexpr int TW = 1 << TWL, TH = 128 / TW;
   constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
@@ -394,7 +396,7 @@ static int launch_wgws(const WgWsArgs& a, hipStream_t st) {
   constexpr int NPT = (128 * MI * 2) / 256 + ((TAPS == 4 ? 4 : 1) * LH * QPITCH * NBF * 2 + 255) / 256;
   constexpr int NBUF = NPT * 4096 * 4 <= 160 * 1024 ? 4 : 3;
   const size_t smem = (size_t)NBUF * NPT * 4096;
-  auto kern = wgrad_ws_kernel<TAPS, TGH, TGW, MI, NBF, TWL, NBUF>;
+  auto kern = wgrad_ws_kernel<TAPS, TGH, TGW, MI, NBF, TWL, NBUF, DUAL>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -437,9 +439,10 @@ int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
 }
 
 int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                 float* slab, WgReduceDesc* desc, hipStream_t st) {
+                 float* slab, WgReduceDesc* desc, hipStream_t st, int dual) {
   const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
   if (!p.ok) return 1;
+  if (dual && (mode != SX_CONV3 || p.MI != 4 || p.NBF != 4 || p.a_tiles != 1 || p.tgk != 0 || p.TWL != 4 || Ca != 64)) return 1;
   WgWsArgs a;
   memset(&a, 0, sizeof(a));
   a.P = (const bf16*)P; a.Q = (const bf16*)Q; a.slab = slab;
@@ -449,7 +452,7 @@ int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, i
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
   a.dbg = getenv("SX_WG_DBG") ? atoi(getenv("SX_WG_DBG")) : 0;
   a.stamps = getenv("SX_WG_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WG_STAMPS"), nullptr, 0) : nullptr;
-  const int rc = p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st);
+  const int rc = dual ? launch_wgws<9, 3, 3, 4, 4, 4, true>(a, st) : (p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st));
   if (rc != SX_OK) return rc;
   desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad; desc->tiled = 1;
   return SX_OK;
