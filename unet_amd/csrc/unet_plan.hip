@@ -163,7 +163,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     wneed(SX_CONV3, b.H, b.W, b.C, b.C);
     wneed(SX_CONV3, b.H, b.W, b.C, b.Cin);
     wneed(SX_CONV1, b.H, b.W, b.C, b.Cin);
-    if (2 * b.C == 64 && b.Cin >= 64) wneed(SX_CONV3, b.H, b.W, 2 * b.C, b.Cin);     // fused conv1 + shortcut launch (WgQueue::add_dual)
+    if (2 * b.C == 64) wneed(SX_CONV3, b.H, b.W, 2 * b.C, b.Cin);     // fused conv1 + shortcut launch (WgQueue::add_dual)
   }
   for (int j = 0; j < D; ++j) {
     const int l = D - 1 - j;
@@ -327,7 +327,7 @@ struct WgQueue {
   // full 128-byte line per pixel (each half on its own is half-line reads of the same lines), the shortcut rows multiply the
   // centre tap only; two descriptors reduce the two row ranges of the slab.  Returns 1 when the shape is not covered.
   int add_dual(int H, int W, int C, int Cb, int Cb_out, const void* P, const void* Q, int q_ld, float* dw3, float* dw1) {
-    if (dtype != SX_BF16 || 2 * C != 64 || Cb < 64) return 1;
+    if (dtype != SX_BF16 || 2 * C != 64 || (Cb != 64 && Cb > 16)) return 1;
     const int64_t bytes = wgrad_ws_slab_bytes(SX_CONV3, B, H, W, 2 * C, Cb);
     if (bytes <= 0) return 1;
     const int64_t need = (int64_t)align_up((size_t)bytes, 256);

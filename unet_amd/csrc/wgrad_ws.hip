@@ -225,11 +225,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   bool it_valid[ITEMS];
 #pragma unroll
   for (int t = 0; t < ITEMS; ++t) {
-    // DUAL (NBF == 4): item t of every wave is tap t (bf = wave), so "is this the centre tap" is known at compile time
+    // DUAL: "is this the centre tap" must be known at compile time.  NBF == 4: item t of every wave is tap t (bf = wave).
+    // NBF == 1: items are dealt t-major and the taps rotated by 4, so the centre tap is item 0 of wave 0 (waves 1-3 then
+    // multiply the shortcut rows for taps 5-7 as well: rows nobody reads).
     const int it = DUAL ? t * 4 + wid : wid * ITEMS + t;
     it_valid[t] = it < NIT;
     const int itc = it_valid[t] ? it : 0;
-    const int tl = itc / NBF, bf = itc - tl * NBF;
+    const int tl = (DUAL && NBF == 1) ? (itc + 4) % 9 : itc / NBF, bf = (DUAL && NBF == 1) ? 0 : itc - tl * NBF;
     const int dy = CT ? 0 : tl / TGW, dx = CT ? 0 : tl - dy * TGW;
     it_tap[t] = TAPS == 9 ? (oy + dy) * 3 + (ox + dx) : (CT ? tl : 0);
     it_bf[t] = bf;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
         if constexpr (ks < 3) wg_issue_tr<(ks + 1) * YS * QPITCH * QB>(Bq[nxt][t], aQ[t][0], aQ[t][1]);
 #pragma unroll
         for (int j = 0; j < MI; ++j)
-          if (!DUAL || j < MI / 2 || t == 4)      // DUAL: fragments 2, 3 of P are the shortcut's dR -- centre tap only (static)
+          if (!DUAL || j < MI / 2 || t == (NBF == 4 ? 4 : 0))   // DUAL: fragments 2, 3 of P are the shortcut's dR -- centre tap only (static)
             acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[cur][t].v(), Af[cur][j].v(), acc[t][j], 0, 0, 0);
       }
     });
@@ -442,7 +444,7 @@ int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, i
                  float* slab, WgReduceDesc* desc, hipStream_t st, int dual) {
   const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
   if (!p.ok) return 1;
-  if (dual && (mode != SX_CONV3 || p.MI != 4 || p.NBF != 4 || p.a_tiles != 1 || p.tgk != 0 || p.TWL != 4 || Ca != 64)) return 1;
+  if (dual && (mode != SX_CONV3 || p.MI != 4 || (p.NBF != 4 && p.NBF != 1) || p.a_tiles != 1 || p.b_tiles != 1 || p.tgk != 0 || p.TWL != 4 || Ca != 64)) return 1;
   WgWsArgs a;
   memset(&a, 0, sizeof(a));
   a.P = (const bf16*)P; a.Q = (const bf16*)Q; a.slab = slab;
@@ -452,7 +454,7 @@ int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, i
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
   a.dbg = getenv("SX_WG_DBG") ? atoi(getenv("SX_WG_DBG")) : 0;
   a.stamps = getenv("SX_WG_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WG_STAMPS"), nullptr, 0) : nullptr;
-  const int rc = dual ? launch_wgws<9, 3, 3, 4, 4, 4, true>(a, st) : (p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st));
+  const int rc = dual ? (p.NBF == 4 ? launch_wgws<9, 3, 3, 4, 4, 4, true>(a, st) : launch_wgws<9, 3, 3, 4, 1, 4, true>(a, st)) : (p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st));
   if (rc != SX_OK) return rc;
   desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad; desc->tiled = 1;
   return SX_OK;
