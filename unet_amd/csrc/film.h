@@ -22,6 +22,7 @@ struct FilmArgs {
   const float* params;   // [B][P]
   float* dparams;        // [B][P] (bwd, accumulated with atomics; caller zeroes)
   int accumulate;
+  float* zero; int zero_n;   // forward only: fp32 words the launch also clears (the network's GroupNorm statistics; saves a memset dispatch)
 };
 
 int film_forward(const FilmArgs& a, hipStream_t st);

@@ -12,6 +12,10 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(FilmArgs a) {
   __shared__ float pv[64];
   const int b = blockIdx.x;
   const FilmGenDesc& d = a.g[blockIdx.y];
+  if (a.zero) {
+    const int nthr = gridDim.x * gridDim.y * blockDim.x;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < a.zero_n; i += nthr) a.zero[i] = 0.f;
+  }
   for (int p = threadIdx.x; p < a.P; p += blockDim.x) pv[p] = a.params[(int64_t)b * a.P + p];
   __syncthreads();
   for (int j = threadIdx.x; j < a.Hf; j += blockDim.x) {

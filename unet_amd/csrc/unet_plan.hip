@@ -219,9 +219,11 @@ static void film_fill(const Plan& p, int k, const float* const* params, float* c
   g.C = b.C;
 }
 
-static int film_run_forward(const Plan& p, int k0, int k1, const float* const* params, void* ws, const float* film_params, hipStream_t st) {
+static int film_run_forward(const Plan& p, int k0, int k1, const float* const* params, void* ws, const float* film_params, hipStream_t st,
+                            float* zero = nullptr, int zero_n = 0) {
   FilmArgs fa;
   memset(&fa, 0, sizeof(fa));
+  fa.zero = zero; fa.zero_n = zero_n;
   fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
   for (int k = k0; k < k1; ++k) film_fill(p, k, params, nullptr, ws, fa.g[k - k0]);
   return film_forward(fa, st);
@@ -550,17 +552,19 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
   SX_REQUIRE(!film || film_params, "sx_unet_encode: FiLM requested without params");
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
-  // clear the encoder's GN statistics (blocks 0..D are laid out first)
-  {
-    // use_film == 2 pairs every decode with the encode before it: the decoder's statistics are cleared here too
-    const int64_t b0 = p.blk[0].st1, b1 = d->use_film == 2 ? p.stats_end : p.blk[D + 1].st1;
-    hipError_t e = hipMemsetAsync(at(ws, b0), 0, (size_t)(b1 - b0), st);
+  // clear the encoder's GN statistics (blocks 0..D are laid out first).  use_film == 2 pairs every decode with the encode
+  // before it: the decoder's statistics are cleared here too, and by the FiLM launch itself instead of a memset dispatch
+  const int64_t zb0 = p.blk[0].st1, zb1 = d->use_film == 2 ? p.stats_end : p.blk[D + 1].st1;
+  const bool film_clears = film && d->use_film == 2;
+  if (!film_clears) {
+    hipError_t e = hipMemsetAsync(at(ws, zb0), 0, (size_t)(zb1 - zb0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
   }
   SX_TRY(sx_pack_input(dt, x, sb, sc, sh, sw, B, d->in_ch, d->H, d->W, at(ws, p.X0), p.in_pad, stream));
   // use_film == 2: encode and decode of this descriptor always see the same film_params, so every generator (the
   // decoder's too) is evaluated here in one launch and sx_unet_decode launches none
-  if (film) SX_TRY(film_run_forward(p, 0, d->use_film == 2 ? 2 * D + 1 : D + 1, params, ws, film_params, st));
+  if (film) SX_TRY(film_run_forward(p, 0, d->use_film == 2 ? 2 * D + 1 : D + 1, params, ws, film_params, st,
+                                    film_clears ? (float*)at(ws, zb0) : nullptr, film_clears ? (int)((zb1 - zb0) / 4) : 0));
   for (int k = 0; k <= D; ++k) {
     bool pooled = false;
     SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st, k < D ? at(ws, p.Pool[k]) : nullptr, k < D ? p.C[k] : 0, &pooled));
