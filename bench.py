@@ -295,7 +295,7 @@ def main():
                                 "mfma_TFLOPs": round(tfs, 2), "mfma_frac": round(tfs / mfma_peak, 4)}
             step_flops = 7.272e9 * a.batch
             line["step_model_tflops"] = round(step_flops * a.steps / dt / 1e12, 2)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU leg is a single-GPU-run item (rank 0, N = 1 only)
             torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "16")))
             v, secs = cpu_baseline(a.cpu_batch, a.cpu_steps)
             line["cpu_baseline"] = {"value": round(v, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
