@@ -234,6 +234,7 @@ def main():
     if world != a.gpus:
         if a.gpus > 1 and world == 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    local = local % max(torch.cuda.device_count(), 1)      # rehearsals: several gloo ranks on one card (SX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L.lib()
@@ -262,7 +263,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
-    loss_last = float(eng.log[max(eng.nlog - 1, 0), 0])
+    lt = eng.log[max(eng.nlog - 1, 0), 0:1].clone()
+    sxdist.all_reduce_sum(lt)            # under DP a rank logs its SHARE of the batch-global loss
+    loss_last = float(lt)
     value = world * a.batch * a.steps / dt
     infer = None if a.no_infer else measure_infer(model, x, p, dtype, a.steps, a.warmup, world, sync, dev)
     line = {

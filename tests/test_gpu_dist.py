@@ -85,8 +85,9 @@ def test_two_rank_engine_steps_equal_single_process(dtype_name, tol):
     try:
         res = sorted([q.get(timeout=75) for _ in range(2)], key=lambda t: t[0])
     except queue.Empty:
-        # seen once in five runs on a shared box: both ranks rendezvous and then stall inside gloo's CUDA staging.  That is
-        # the transport of this TEST (RCCL needs one device per rank, the box has one), not the protocol under test.
+        # belt and braces: gloo's ASYNCHRONOUS CUDA path stalled with two ranks on one card (unet_amd.dist stages gloo
+        # collectives through the host since).  gloo is the transport of this TEST (RCCL needs one device per rank, the box
+        # has one), not the protocol under test.
         for p in procs:
             p.terminate()
         for p in procs:

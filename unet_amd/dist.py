@@ -59,7 +59,8 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # SX_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a one-card box; RCCL wants a device per rank)
+        backend = os.environ.get("SX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():
@@ -75,6 +76,15 @@ class _Done:
 def all_reduce_sum(t, async_op=False):
     """In-place SUM all-reduce of a tensor (no-op when there is one rank)."""
     if not is_active():
+        return _Done() if async_op else t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        # gloo is the stand-in transport of the tests / one-card rehearsals.  Its asynchronous CUDA path (worker threads staging
+        # through pinned memory while the caller keeps launching kernels) stalled with two ranks sharing one GPU (both ranks
+        # stuck in wait(), reproducibly at the benchmark's sizes); stage through the host here, synchronously.
+        torch.cuda.current_stream().synchronize()
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        t.copy_(c)
         return _Done() if async_op else t
     h = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
     return h if async_op else t

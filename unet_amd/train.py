@@ -201,7 +201,7 @@ class TrainEngine:
         if self.world > 1 and closing:
             h_dec = sxdist.all_reduce_sum(self.flat_g[:self.n_dec], async_op=True)
         h_bot = None
-        if self.world > 1 and closing and self.n_bot > self.n_dec:
+        if self.world > 1 and closing and self.n_bot > self.n_dec and not os.environ.get("SX_DP_NO_SPLIT"):
             sess.encode_backward(fp, flags | L.SX_BWD_ONLY_BOTTLENECK)
             h_bot = sxdist.all_reduce_sum(self.flat_g[self.n_dec:self.n_bot], async_op=True)
             sess.encode_backward(fp, flags | L.SX_BWD_AFTER_BOTTLENECK)
