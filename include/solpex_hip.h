@@ -319,6 +319,7 @@ int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const 
                                   share of FILM_DPARAMS) and the decoder half's GroupNorm affine and bias gradients are finished
                                   inside sx_unet_encode_backward (one launch for all of them); film_dec.* and
                                   decoders.*.net.{1,4}.*, up_convs.*.bias, out.bias gradients are complete only after that call */
+#define SX_BWD_NO_DPARAMS       64 /* skip FILM_DPARAMS (the gradient w.r.t. the FiLM inputs): a training step does not read it */
 #define SX_BWD_ONLY_BOTTLENECK  16 /* sx_unet_encode_backward only: back-propagate the bottleneck block and finish ITS convolution
                                       weight gradients (bot.net.{0,3}.weight, bot.shortcut.weight), then return ...            */
 #define SX_BWD_AFTER_BOTTLENECK 32 /* ... and a second call with this flag does everything else (the encoder levels, every

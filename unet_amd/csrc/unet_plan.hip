@@ -234,7 +234,7 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   FilmArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
-  fa.dparams = (float*)at(ws, p.dparams);
+  fa.dparams = (flags & SX_BWD_NO_DPARAMS) ? nullptr : (float*)at(ws, p.dparams);   // training does not need d(loss)/d(params)
   fa.accumulate = (flags & SX_BWD_ACCUMULATE) ? 1 : 0;
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
   for (int k = k0; k < k1; ++k) film_fill(p, k, params, wg ? grads : nullptr, ws, fa.g[k - k0]);

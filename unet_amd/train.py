@@ -194,8 +194,9 @@ class TrainEngine:
         sess.encode(x, fp)
         sess.decode(fp, drop_table)
         out = self._loss_end(sess, bufs, y, begun, lg, True, 1.0 / max(int(grad_accum_steps), 1))
-        flags = L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0)
-        sess.decode_backward(fp, drop_table, flags | L.SX_BWD_ZERO_DPARAMS)
+        flags = (L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | L.SX_BWD_NO_DPARAMS |
+                 (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0))
+        sess.decode_backward(fp, drop_table, flags)
         h_dec = None
         closing = step_now and (self.accum + 1 >= max(int(grad_accum_steps), 1))
         if self.world > 1 and closing:
