@@ -117,6 +117,17 @@ int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int 
                   const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
                   float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* sx_conv_wgrad_static: sx_conv_wgrad without the workspace argument, for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the
+ * reference.  The split-K slabs live in a static device array of SX_WGRAD_STATIC_BYTES that every GPU the library runs
+ * on holds until the process ends; the call allocates and frees nothing.  Problems whose slabs
+ * (sx_conv_wgrad_workspace_bytes) exceed that size are rejected with SX_ERR_UNSUPPORTED.  All calls on one GPU share
+ * the array: calls that overlap on one GPU (different streams or threads) race. */
+#define SX_WGRAD_STATIC_BYTES (32u << 20)
+int sx_conv_wgrad_static(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
+                         const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                         float* dw, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm + SiLU and the DoubleConv block output, forward and backward (models.py:64-71,80,
  * 152-156).  stats = fp32 [B][groups][2] from sx_conv_forward.  HW = pixels per sample.

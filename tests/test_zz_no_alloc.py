@@ -1,0 +1,59 @@
+"""GPU: sx_conv_wgrad_static -- the weight gradient for callers that cannot allocate (its split-K slabs live in a static
+device array) -- against sx_conv_wgrad with a caller workspace, through the C ABI, bit for bit (same kernels, same
+reduction order), on two calls in a row, the second with a smaller input; and the size limit is enforced.
+Collected last (file name): a failure here must not hide the other GPU tests under `pytest -x`."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t, dtype):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16 if dtype == 1 else torch.float32).cuda()
+
+
+def _both(L, dtype, mode, B, H, W, Cin, Cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 3 if mode == 0 else 1
+    xd = _nhwc(torch.randn(B, Cin, H, W, generator=g), dtype)
+    dyd = _nhwc(torch.randn(B, Cout, H, W, generator=g), dtype)
+    lib = L.lib()
+    nb = lib.sx_conv_wgrad_workspace_bytes(mode, B, H, W, Cout, Cin)
+    assert 0 < nb <= L.SX_WGRAD_STATIC_BYTES
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    ref = torch.full((Cout, Cin, k, k), 0.5, dtype=torch.float32, device="cuda")
+    got = ref.clone()
+    L.check(lib.sx_conv_wgrad(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
+                              L.ptr(ref), 1, L.ptr(ws), nb, L.stream_ptr()), "sx_conv_wgrad")
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    L.check(lib.sx_conv_wgrad_static(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
+                                     L.ptr(got), 1, L.stream_ptr()), "sx_conv_wgrad_static")
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 1.0
+    return ref.cpu(), got.cpu()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_static_scratch_wgrad_matches_workspace_wgrad_twice(dtype):
+    from unet_amd import _lib as L
+    # first call: a level-1 shape of the benchmark network (many splits -> most of the slabs in use) ...
+    ref, got = _both(L, dtype, 0, 8, 64, 32, 64, 64, seed=1)
+    assert torch.equal(ref, got)
+    # ... then a smaller problem on the same GPU: stale slab contents of the first call must not leak in
+    ref, got = _both(L, dtype, 0, 2, 16, 8, 16, 32, seed=2)
+    assert torch.equal(ref, got)
+    ref, got = _both(L, dtype, 1, 3, 12, 10, 32, 16, seed=3)
+    assert torch.equal(ref, got)
+
+
+def test_static_scratch_rejects_oversized_problems():
+    from unet_amd import _lib as L
+    lib = L.lib()
+    B, H, W, Ca, Cb = 64, 16, 8, 1024, 1024        # slabs of 9 x 1024 x 1024 fp32 = 36 MiB each
+    assert lib.sx_conv_wgrad_workspace_bytes(0, B, H, W, Ca, Cb) > L.SX_WGRAD_STATIC_BYTES
+    t = torch.zeros(16, device="cuda")
+    with pytest.raises(ValueError, match="static scratch"):
+        L.check(lib.sx_conv_wgrad_static(1, 0, B, H, W, Ca, Cb, Ca, Cb, L.ptr(t), Ca, L.ptr(t), Cb, H, W, L.ptr(t), 0,
+                                         L.stream_ptr()), "sx_conv_wgrad_static")

@@ -20,6 +20,7 @@ SX_ERR_INVALID, SX_ERR_UNSUPPORTED, SX_ERR_HIP = -1, -2, -3
 SX_BWD_WEIGHT_GRADS, SX_BWD_ACCUMULATE, SX_BWD_ZERO_DPARAMS, SX_BWD_DEFER_FILM = 1, 2, 4, 8
 SX_BWD_ONLY_BOTTLENECK, SX_BWD_AFTER_BOTTLENECK, SX_BWD_NO_DPARAMS = 16, 32, 64
 SX_NORM_LOG, SX_NORM_LINEAR, SX_NORM_SYMLOG = 0, 1, 2
+SX_WGRAD_STATIC_BYTES = 32 << 20
 PX_KINDS = {"huber": 0, "l1": 1, "mse": 2}
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "sx_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sx_conv_wgrad_workspace_bytes": (_l, [_i] * 6),
     "sx_conv_wgrad": (_i, [_i] * 9 + [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p]),
+    "sx_conv_wgrad_static": (_i, [_i] * 9 + [_p, _i, _p, _i, _i, _i, _p, _i, _p]),
     "sx_gn_silu_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p]),
     "sx_block_out_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "sx_block_out_pool_forward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p]),

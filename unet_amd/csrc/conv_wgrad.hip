@@ -16,6 +16,7 @@
 // (deterministic) straight into the parameter-gradient tensor in PyTorch layout.
 #include "wgrad_common.h"
 #include <algorithm>
+#include <mutex>
 
 namespace sx {
 
@@ -410,4 +411,51 @@ extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, i
   SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, workspace, workspace_bytes, &d, (hipStream_t)stream));
   d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = accumulate;
   return wgrad_reduce_multi(&d, 1, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ sx_conv_wgrad_static
+// The same weight gradient for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the split-K slabs live in a file-scope device array instead of a caller
+// workspace.  Every GPU the library runs on holds its own copy of the array (SX_WGRAD_STATIC_BYTES) until the process
+// ends; `scratch` below is only the host-side handle of the symbol -- the per-device address comes from
+// hipGetSymbolAddress, once per device, and that address is what the kernels receive.
+namespace sx {
+static __device__ __align__(256) unsigned char scratch[SX_WGRAD_STATIC_BYTES];
+static constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES];      // device address of `scratch` on each device, filled on first use
+static std::mutex g_scratch_mu;
+
+static int scratch_on_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  SX_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "sx_conv_wgrad_static: device ordinal %d outside 0..%d", dev, MAX_DEVICES - 1);
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+    SX_REQUIRE(p && ((uintptr_t)p % 256) == 0, "sx_conv_wgrad_static: bad scratch address");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return SX_OK;
+}
+}  // namespace sx
+
+extern "C" int sx_conv_wgrad_static(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
+                                    const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                                    float* dw, int accumulate, void* stream) {
+  const int64_t need = sx_conv_wgrad_workspace_bytes(mode, B, H, W, Ca, Cb);
+  SX_REQUIRE(need >= 0, "sx_conv_wgrad_static: bad mode %d", mode);
+  if (need > (int64_t)SX_WGRAD_STATIC_BYTES) {
+    set_error("sx_conv_wgrad_static: this problem needs %lld bytes of split-K slabs, the static scratch holds %lld "
+              "(use sx_conv_wgrad with a caller workspace)", (long long)need, (long long)SX_WGRAD_STATIC_BYTES);
+    return SX_ERR_UNSUPPORTED;
+  }
+  void* ptr = nullptr;
+  SX_TRY(scratch_on_current_device(&ptr));
+  // every slab element the reduction reads is written by the split-K kernel first: nothing to clear between calls
+  return sx_conv_wgrad(dtype, mode, B, H, W, Ca, Cb, Ca_out, Cb_out, P, p_ld, Q, q_ld, Hq, Wq, dw, accumulate, ptr,
+                       (int64_t)SX_WGRAD_STATIC_BYTES, stream);
 }
