@@ -1,0 +1,165 @@
+"""GPU: parity at the BENCHMARKED shapes (BASELINE configs[1] and configs[3]) against the CPU oracle on the same weights and
+batch -- the instantiations the timed step runs (16-wide weights-stationary tiles, persistent weight gradients, fused
+conv1 + shortcut launches) with non-zero, per-sample masks.
+
+Tolerances (north star): fp32 tier <= 1e-4 on the loss, <= 5e-4 per-tensor gradient L2; bf16 tier <= 1e-2 on the loss,
+per-tensor gradients <= 6e-2 relative L2 with cosine >= 0.998 (every activation and activation gradient is stored in bf16).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOSS = dict(lam_w=0.5, lam_grad=0.1, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
+            multiscale=0, ms_weight=0.5, grad_ds=2)
+LR, WD, CLIP = 3e-4, 1e-4, 1.0
+
+
+def _oracle_step(cfg, sd, bt, w, cw):
+    """One full training step of the CPU oracle: loss, every gradient, clipped AdamW update (train.py:183-233)."""
+    from oracle import unet_ref, loss_ref, optim_ref
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = unet_ref.unet_forward(sdr, cfg, bt["x"], bt["params"])
+    loss = loss_ref.masked_weighted_loss(pred, bt["y"], bt["mask"], w=w, channel_weights=cw, **LOSS)
+    loss.backward()
+    names = list(sdr)
+    grads = {k: sdr[k].grad.detach().clone() for k in names}
+    clipped, total = optim_ref.clip_grad_norm([grads[k] for k in names], CLIP)
+    new = {}
+    for k, g in zip(names, clipped):
+        z = torch.zeros_like(g)
+        new[k], _, _ = optim_ref.adamw_step(sd[k], g, z, z, 1, LR, weight_decay=WD)
+    mae = loss_ref.mae_norm(pred.detach(), bt["y"], bt["mask"])
+    return float(loss.detach()), grads, new, float(total), float(mae), pred.detach()
+
+
+@pytest.fixture(scope="module")
+def cfg2_case():
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from oracle import loss_ref
+    from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8
+    torch.set_num_threads(16)
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    sd = init_state_dict(cfg, seed=0)
+    bt = make_batch(64, 128, 64, seed=1234, jitter_masks=True)          # per-sample masks, ~50 % fill
+    w = torch.from_numpy(loss_ref.edge_weights(bt["mask"][0, 0].numpy()))
+    cw = torch.tensor(CHANNEL_WEIGHTS_8)
+    ref = _oracle_step(cfg, sd, bt, w, cw)
+    return cfg, sd, bt, w, cw, ref
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_g,cos_min", [(torch.float32, 1e-4, 5e-4, 0.999999), (torch.bfloat16, 1e-2, 6e-2, 0.998)])
+def test_cfg2_train_step_against_oracle(cfg2_case, dtype, tol_loss, tol_g, cos_min):
+    """TrainEngine.train_step at batch 64, 128x64, cfg A: loss, mae_norm, every parameter gradient, the gradient norm the
+    clip uses, and the parameters after clip + AdamW, against one oracle step."""
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    cfg, sd, bt, w, cw, (loss_ref_v, g_ref, p_ref, gnorm_ref, mae_ref, _) = cfg2_case
+    model = UNet(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    eng = TrainEngine(model, dtype=dtype, lr=LR, weight_decay=WD, clip_grad=CLIP, channel_weights=[float(v) for v in cw],
+                      w_map=w, loss_opts=LOSS)
+    x, y, m, p = (bt[k].cuda() for k in ("x", "y", "mask", "params"))
+    out = eng.train_step(x, y, m, p, lam_grad=LOSS["lam_grad"])
+    torch.cuda.synchronize()
+    loss = float(out[0])
+    assert abs(loss - loss_ref_v) < tol_loss * abs(loss_ref_v), (loss, loss_ref_v)
+    mae = float(out[1]) / max(float(out[2]), 1e-8)
+    assert abs(mae - mae_ref) < max(tol_loss, 1e-4) * mae_ref, (mae, mae_ref)
+    assert abs(float(eng.gnorm) - gnorm_ref) < tol_g * gnorm_ref, (float(eng.gnorm), gnorm_ref)
+    # the arena still holds the gradient the optimizer consumed
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    worst = (0.0, "")
+    for k, q in model.named_parameters():
+        gd, rd = q.grad.detach().cpu().double().reshape(-1), g_ref[k].double().reshape(-1)
+        err = float((gd - rd).norm()) / max(float(rd.norm()), 0.05 * gmax if dtype == torch.bfloat16 else 1e-3 * gmax)
+        worst = max(worst, (err, k))
+        assert err < tol_g, (k, err, float(rd.norm()))
+        if float(rd.norm()) > 0.05 * gmax:
+            assert float(torch.dot(gd, rd) / (gd.norm() * rd.norm())) > cos_min, k
+    # parameters after clip + AdamW.  Step 1 of Adam moves a weight by ~lr * g / |g| whatever |g|, so a gradient element
+    # within rounding of zero may flip its update: the update is compared as ONE vector over all parameters (flips of
+    # near-zero elements are the tolerance; per-tensor checks of 32-element tensors would hinge on single flips)
+    du = torch.cat([(q.detach().cpu().double() - sd[k].double()).reshape(-1) for k, q in model.named_parameters()])
+    dr = torch.cat([(p_ref[k].double() - sd[k].double()).reshape(-1) for k, _ in model.named_parameters()])
+    upd_err = float((du - dr).norm() / dr.norm())
+    assert upd_err < (5e-3 if dtype == torch.float32 else 0.15), upd_err
+    for k, q in model.named_parameters():
+        assert rel_err(q.detach().cpu(), p_ref[k]) < (1e-3 if dtype == torch.float32 else 2e-2), k
+    print(f"[cfg2 {dtype}] loss {loss:.6f} vs {loss_ref_v:.6f}; worst gradient {worst}; update vector error {upd_err:.3e}")
+
+
+def test_cfg2_forward_eval_after_train_step_uses_updated_weights(cfg2_case):
+    """eval forward -> train_step -> eval forward: the second forward must see the parameters AdamW just wrote through raw
+    pointers (the packed-weight cache cannot key on tensor versions alone)."""
+    from oracle import unet_ref
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    cfg, sd, bt, w, cw, ref = cfg2_case
+    model = UNet(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    x, y, m, p = (bt[k][:8].cuda() for k in ("x", "y", "mask", "params"))
+    eng = TrainEngine(model, dtype=torch.float32, lr=5e-2, weight_decay=WD, clip_grad=CLIP, w_map=w, loss_opts=LOSS)
+    model.eval()
+    with torch.no_grad():
+        y0 = model(x, params=p).float().cpu()          # fills the packed-weight cache (parameters already in the arena)
+    assert rel_err(y0, ref[5][:8]) < 1e-4
+    model.train()
+    for _ in range(2):
+        eng.train_step(x, y, m, p, lam_grad=LOSS["lam_grad"])
+    model.eval()
+    with torch.no_grad():
+        y1 = model(x, params=p).float().cpu()
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        r1 = unet_ref.unet_forward(sd1, cfg, bt["x"][:8], bt["params"][:8])
+    assert rel_err(y1, y0) > 1e-2          # lr 5e-2: the weights really moved
+    assert rel_err(y1, r1) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol_hist,tol_p", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 1e-2, 2e-2)])
+def test_config4_chunk1024_against_oracle(dtype, tol_hist, tol_p):
+    """BASELINE configs[3]: the batched inverse at its per-GPU chunk (1024 cases, cfg A, 128x64), a few Adam steps; eight
+    sampled cases against the oracle's per-case loop (B = 1), including the first and last case of the chunk."""
+    from oracle import inverse_ref, unet_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.inverse import batched_inverse
+    from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8
+    torch.set_num_threads(16)
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    sd = init_state_dict(cfg, seed=3)
+    model = UNet(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    N, steps = 1024, 3
+    bt = make_batch(N, 128, 64, seed=41, jitter_masks=True)
+    mask, p_true = bt["mask"], bt["params"]
+    picks = [0, 1, 63, 64, 500, 777, 1022, 1023]
+    cw = torch.tensor(CHANNEL_WEIGHTS_8)
+    # targets: the oracle's own forward for the sampled cases, noise elsewhere (cases are independent)
+    y_true = bt["y"].clone()
+    with torch.no_grad():
+        for n in picks:
+            y_true[n:n + 1] = unet_ref.unet_forward(sd, cfg, mask[n:n + 1], p_true[n:n + 1])
+    p0 = 0.25 * torch.randn(N, 5, generator=torch.Generator().manual_seed(9))
+    kw = dict(steps=steps, lr=5e-2, reg=1e-4, clip=4.0, patience=0, tol=1e-6)
+    res = batched_inverse(model, mask.cuda(), y_true.cuda(), p0.cuda(), channel_weights=cw, steps=steps, lr=5e-2, reg=1e-4,
+                          clip_scaled=4.0, early_stop_patience=0, batch=1024, dtype=dtype, return_history=True)
+    torch.cuda.synchronize()
+    hist = res["loss_history"].cpu().numpy()
+    assert np.isfinite(hist).all() and torch.isfinite(res["p_scaled"]).all()
+    fidx = list(range(8))
+    for n in picks:
+        p_fin, fit, mae, losses = inverse_ref.inverse_case(sd, cfg, mask[n:n + 1], y_true[n:n + 1], p0[n:n + 1], fidx, cw, **kw)
+        # the fit is a DIFFERENCE quantity: predictions within the bf16 bar (1e-2 relative) move it by ~1e-4 of the signal
+        # power whatever its own size, hence the absolute floor in the bf16 tier
+        atol = 1e-7 if dtype == torch.float32 else 3e-4
+        assert np.allclose(hist[:, n], np.asarray(losses), rtol=tol_hist, atol=atol), (n, hist[:, n], losses)
+        assert float((res["p_scaled"][n].cpu() - p_fin).abs().max()) < tol_p, (n, res["p_scaled"][n].cpu(), p_fin)
+        assert abs(float(res["fit"][n]) - fit) < 10 * tol_hist * abs(fit) + atol, (n, float(res["fit"][n]), fit)

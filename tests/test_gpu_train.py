@@ -176,7 +176,7 @@ def test_engine_dp_code_path_single_process_equals_plain_step():
         m = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
         m.load_state_dict(sd)
         eng = TrainEngine(m.cuda().train(), dtype=torch.float32, lr=1e-3, clip_grad=1.0)
-        eng.world = world
+        eng.world, eng.dp = world, world > 1
         assert eng.n_dec < eng.n_bot < eng.flat_g.numel()
         eng.train_step(bt["x"], bt["y"], bt["mask"], bt["params"], lam_grad=0.1)
         torch.cuda.synchronize()

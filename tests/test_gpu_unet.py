@@ -168,6 +168,28 @@ def test_errors_and_boundaries():
     assert len(m.state_dict()) == 61
 
 
+def test_unet_cfgA_full_size_summary_bf16(golden):
+    """The same reference vectors (cfg A, 128x64) through the bf16 tier -- the tile configurations of the benchmarked
+    network (16-wide weights-stationary tiles, persistent weight gradients) at the north-star bf16 bar."""
+    g = golden("unet_cfgA_summary.npz")
+    model, pred, b, loss, params = run_case(g, torch.bfloat16)
+    assert pred.dtype == torch.bfloat16
+    assert rel_err(pred.detach().float().cpu(), g["pred"]) < 1e-2
+    assert abs(float(b.detach().float().norm()) - float(g["b_norm"])) < 1e-2 * float(g["b_norm"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    named = dict(model.named_parameters())
+    gmax = float(np.max(g["grad_norms"]))
+    for n, gn in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        assert abs(float(named[n].grad.norm()) - gn) < 6e-2 * max(gn, 0.05 * gmax), n
+    for k in g.files:
+        if k.startswith("grad::"):
+            gd, rd = named[k[6:]].grad.cpu().double().reshape(-1), torch.from_numpy(g[k]).double().reshape(-1)
+            assert float((gd - rd).norm()) < 6e-2 * max(float(rd.norm()), 0.05 * gmax), k
+            if float(rd.norm()) > 0.05 * gmax:
+                assert float(torch.dot(gd, rd) / (gd.norm() * rd.norm())) > 0.998, k
+    assert rel_err(params.grad.cpu(), g["dparams"]) < 6e-2
+
+
 def test_full_size_properties_cfg2_shape():
     """cfg 2 shape (B=64, 128x64, bf16): size-independent properties instead of an oracle run.
     (1) samples are independent: a batch of 64 equals the same samples run 8 at a time (up to the

@@ -454,6 +454,64 @@ def inverse_lbfgs_case():
          fit_final=np.asarray(fit_fin))
 
 
+def loaders_case():
+    """solpex/data.py:467-572 make_loaders on a synthetic npz (multi-channel Y with non-finite entries, per-sample masks,
+    `throughput_ratio` parameter transform, Log / SymLog / Linear normalizers): fitted statistics, parameter scaler, the
+    train / val split and the first batches.  The npz arrays travel inside the fixture."""
+    import tempfile
+    rng = np.random.default_rng(11)
+    N, H, W = 41, 16, 8
+    mask = np.zeros((N, H, W), np.float32)
+    for i in range(N):
+        mask[i, 2 + i % 3:H - 2, 1:W - 1 - i % 2] = 1
+    Y = rng.normal(size=(N, 3, H, W)).astype(np.float32) * 10
+    Y[:, 0] = np.abs(Y[:, 0]) + 0.5
+    Y[1, 0, 3, 3] = np.nan
+    Y[2, 1, 4, 2] = np.inf
+    Y[3, 2, 5, 3] = -np.inf
+    X = np.exp(rng.normal(size=(N, 5))).astype(np.float32)
+    X[:, 0] *= 1e21
+    X[:, 2] *= 3e20
+    y_keys_all = np.array(["Te", "S", "ne"])
+    param_keys = np.array(["Gamma_D2", "Ptot_W", "n_core", "dna", "hci"])
+    out = dict(Y=Y, mask=mask, X=X, y_keys_all=y_keys_all, param_keys_in=param_keys)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "d.npz")
+        np.savez(path, Y=Y, y_keys=y_keys_all, mask=mask, X=X, param_keys=param_keys)
+        norms = dict(Te=ref_data.MaskedLogStandardizer(eps=1.0), S=ref_data.MaskedSymLogStandardizer(scale=5.0),
+                     ne=ref_data.MaskedLinearStandardizer())
+        tl, vl, norm, P, hw, (pmu, pstd), pt, pk = ref_data.make_loaders(
+            path, inputs_mode="params", batch_size=8, split=0.85, seed=42, device="cpu", y_keys=["Te", "S", "ne"],
+            norms_by_name=norms, param_transform="throughput_ratio")
+        out.update(P=P, H=hw[0], W=hw[1], param_mu=pmu, param_std=pstd, param_transform=np.asarray(pt),
+                   param_keys_out=np.array([str(k) for k in pk]), idx_tr=np.asarray(tl.dataset.indices),
+                   idx_va=np.asarray(vl.dataset.indices), n_train_batches=len(tl), n_val_batches=len(vl))
+        for k in ("Te", "S", "ne"):
+            out[f"mu_{k}"] = np.float64(norm.norms[k].mu)
+            out[f"sigma_{k}"] = np.float64(norm.norms[k].sigma)
+        torch.manual_seed(123)
+        bt = next(iter(tl))
+        bv = next(iter(vl))
+        for tag, b in (("tr", bt), ("va", bv)):
+            for k in ("x", "y", "mask", "params", "idx"):
+                out[f"{tag}_{k}"] = b[k]
+        # every validation batch's idx (order of an un-shuffled loader) and the last, short, training batch size
+        out["va_idx_all"] = np.concatenate([np.asarray(b["idx"]) for b in vl])
+        # legacy single-output path: y_keys=None -> MaskedLogStandardizer(eps=1) on y_key="Te", no parameter transform
+        tl1, vl1, norm1, P1, hw1, (pmu1, pstd1), pt1, pk1 = ref_data.make_loaders(path, inputs_mode="params", batch_size=4,
+                                                                                split=0.7, seed=7, device="cpu", y_key="Te")
+        out.update(leg_mu=np.float64(norm1.mu), leg_sigma=np.float64(norm1.sigma), leg_param_mu=pmu1, leg_param_std=pstd1,
+                   leg_idx_tr=np.asarray(tl1.dataset.indices), leg_y0=vl1.dataset[0]["y"], leg_param_keys=np.array([str(k) for k in pk1]))
+        # autoencoder mode: x = normalised y, no parameter scaler
+        norms = dict(Te=ref_data.MaskedLogStandardizer(eps=1.0), S=ref_data.MaskedSymLogStandardizer(scale=5.0))
+        tl2, vl2, norm2, P2, hw2, (pmu2, pstd2), pt2, pk2 = ref_data.make_loaders(
+            path, inputs_mode="autoencoder", batch_size=8, y_keys=["Te", "S"], norms_by_name=norms, device="cpu")
+        assert pmu2 is None
+        b2 = next(iter(vl2))
+        out.update(ae_x=b2["x"], ae_params=b2["params"], ae_mu_S=np.float64(norm2.norms["S"].mu))
+    save("loaders_case.npz", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     prod = dict(lam_grad=0.1, lam_w=0.5, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
@@ -474,6 +532,7 @@ def main():
     train_case()
     inverse_case()
     inverse_lbfgs_case()
+    loaders_case()
 
 
 if __name__ == "__main__":

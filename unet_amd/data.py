@@ -408,6 +408,19 @@ class _Positions(Dataset):
         return int(i)
 
 
+def rank_share(global_batch, rank, world, pad):
+    """Rank `rank`'s rows of one GLOBAL batch of positions (a LongTensor): the batch is cut into `world` equal consecutive
+    shares; a short last batch is padded with `pad` (the position of an all-zero-mask sample, which adds nothing to any
+    masked sum), so every rank sees the same number of rows and of batches.  Concatenating the shares of ranks 0..world-1
+    gives the global batch back (plus padding): DP-N at per-rank batch b reproduces the single-process run at batch N*b."""
+    g = int(global_batch.numel())
+    per = (g + world - 1) // world
+    mine = global_batch[rank * per:(rank + 1) * per]
+    if mine.numel() < per:
+        mine = torch.cat([mine, torch.full((per - mine.numel(),), int(pad), dtype=global_batch.dtype)])
+    return mine
+
+
 class ResidentLoader:
     """Device-resident replacement of `DataLoader(Subset(SOLPSDataset, indices), batch_size, shuffle)`.
 
@@ -418,7 +431,11 @@ class ResidentLoader:
     host loader for a given torch seed; tensors are already on `device` (`idx` stays a host LongTensor).
     """
 
-    def __init__(self, subset, batch_size, shuffle, device, drop_last=False, chunk=256):
+    def __init__(self, subset, batch_size, shuffle, device, drop_last=False, chunk=256, rank=None, world=None):
+        """Under data parallelism (`rank` / `world`, default: the process group's) `batch_size` is the PER-RANK batch: the
+        batch order is drawn for global batches of world * batch_size from a generator all ranks seed alike, and each rank
+        gathers its share (`rank_share`)."""
+        from . import dist as sxdist
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("ResidentLoader needs a CUDA (ROCm) device; use the host DataLoader otherwise")
@@ -429,32 +446,55 @@ class ResidentLoader:
         if not isinstance(ds, SOLPSDataset):
             raise TypeError("ResidentLoader wraps a SOLPSDataset (or a Subset of one)")
         self.dataset, self.batch_size, self.device = subset, int(batch_size), device
-        self._order = DataLoader(_Positions(len(indices)), batch_size=batch_size, shuffle=shuffle, drop_last=drop_last)
-        self._indices = torch.from_numpy(indices)
+        self._shuffle, self._drop_last = bool(shuffle), bool(drop_last)
+        self._indices = torch.cat([torch.from_numpy(indices), torch.tensor([-1], dtype=torch.int64)])   # [n] = padding row
         n = len(indices)
         self.n, self.C, self.H, self.W = n, ds.C_out, ds.H, ds.W
+        self.shard(sxdist.rank() if rank is None else rank, sxdist.world_size() if world is None else world)
         self.autoencoder = ds.inputs == "autoencoder"
         mask = (ds.mask[indices] > 0.5).astype(np.float32)[:, None]                     # (n,1,H,W), data.py:369-370
-        self.mask = torch.from_numpy(mask).to(device)
-        self.y = torch.empty(n, self.C, self.H, self.W, dtype=torch.float32, device=device)
+        # one extra all-zero row at position n: the padding sample of a short last global batch under data parallelism
+        self.mask = torch.zeros(n + 1, 1, self.H, self.W, dtype=torch.float32, device=device)
+        self.mask[:n] = torch.from_numpy(mask).to(device)
+        self.y = torch.zeros(n + 1, self.C, self.H, self.W, dtype=torch.float32, device=device)
         for i0 in range(0, n, chunk):
             sel = indices[i0:i0 + chunk]
             raw = ds.Y[sel][:, ds.ks] if ds._has_Y else ds.Te[sel][:, None]
             raw = np.nan_to_num(np.ascontiguousarray(raw, dtype=np.float32), nan=0.0, posinf=0.0, neginf=0.0)
-            m = self.mask[i0:i0 + chunk]
+            m = self.mask[i0:min(i0 + chunk, n)]
             if ds.normalizer is None:
-                self.y[i0:i0 + chunk] = torch.from_numpy(raw * mask[i0:i0 + chunk]).to(device)
+                self.y[i0:i0 + len(sel)] = torch.from_numpy(raw * mask[i0:i0 + chunk]).to(device)
             else:
-                self.y[i0:i0 + chunk] = ds.normalizer.transform(torch.from_numpy(raw).to(device), m)
-        self.params = torch.from_numpy(np.ascontiguousarray(ds.params[indices], dtype=np.float32)).to(device)
+                self.y[i0:i0 + len(sel)] = ds.normalizer.transform(torch.from_numpy(raw).to(device), m)
+        prm = np.ascontiguousarray(ds.params[indices], dtype=np.float32)
+        self.params = torch.from_numpy(np.concatenate([prm, np.zeros((1, prm.shape[1]), np.float32)])).to(device)
         self.P = self.params.shape[1]
         self.geo = None
         if not self.autoencoder and ds.Rn is not None:
             self.geo = torch.from_numpy(np.stack([ds.Rn, ds.Zn]).astype(np.float32)).to(device).contiguous()
         self.in_ch = self.C if self.autoencoder else (3 if self.geo is not None else 1)
 
+    def shard(self, rank, world):
+        """(Re)define this loader as rank `rank` of `world` data-parallel ranks."""
+        self.rank, self.world = int(rank), max(int(world), 1)
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"ResidentLoader: rank {rank} outside 0..{world - 1}")
+        # world == 1: torch's global RNG decides the order, exactly as the reference's DataLoader(shuffle=True) does
+        self._gen = torch.Generator() if self.world > 1 else None
+        self._order = DataLoader(_Positions(self.n), batch_size=self.batch_size * self.world, shuffle=self._shuffle,
+                                 drop_last=self._drop_last, generator=self._gen)
+        return self
+
     def __len__(self):
         return len(self._order)
+
+    def _sync_seed(self):
+        """All ranks must draw the same permutation: rank 0's next value of the global RNG seeds every rank's generator."""
+        from . import dist as sxdist
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        if sxdist.is_active() and sxdist.world_size() == self.world:
+            seed = sxdist.broadcast0(seed, self.device)
+        self._gen.manual_seed(int(seed))
 
     def _gather(self, src, n_src, row, pos, nb, dst, dst_stride):
         L.check(L.lib().sx_gather_rows(L.ptr(src), row, n_src, L.ptr(pos), nb, row, L.ptr(dst), dst_stride, L.stream_ptr()),
@@ -462,25 +502,29 @@ class ResidentLoader:
 
     def __iter__(self):
         HW = self.H * self.W
+        if self.world > 1:
+            self._sync_seed()
         for pos in self._order:                      # host LongTensor of positions inside the subset
-            nb = int(pos.numel())
             if int(pos.min()) < 0 or int(pos.max()) >= self.n:
                 raise IndexError("ResidentLoader: sampler produced an index outside the subset")
+            if self.world > 1:
+                pos = rank_share(pos, self.rank, self.world, self.n)
+            nb = int(pos.numel())
             pos_d = pos.to(self.device, non_blocking=True)
             y = torch.empty(nb, self.C, self.H, self.W, dtype=torch.float32, device=self.device)
             mask = torch.empty(nb, 1, self.H, self.W, dtype=torch.float32, device=self.device)
-            self._gather(self.y, self.n, self.C * HW, pos_d, nb, y, self.C * HW)
-            self._gather(self.mask, self.n, HW, pos_d, nb, mask, HW)
+            self._gather(self.y, self.n + 1, self.C * HW, pos_d, nb, y, self.C * HW)
+            self._gather(self.mask, self.n + 1, HW, pos_d, nb, mask, HW)
             params = torch.empty(nb, self.P, dtype=torch.float32, device=self.device)
             if self.P > 0:
-                self._gather(self.params, self.n, self.P, pos_d, nb, params, self.P)
+                self._gather(self.params, self.n + 1, self.P, pos_d, nb, params, self.P)
             if self.autoencoder:
                 x = y.clone()
             elif self.geo is None:
                 x = mask.clone()
             else:
                 x = torch.empty(nb, 3, self.H, self.W, dtype=torch.float32, device=self.device)
-                self._gather(self.mask, self.n, HW, pos_d, nb, x, 3 * HW)
+                self._gather(self.mask, self.n + 1, HW, pos_d, nb, x, 3 * HW)
                 zero = torch.zeros(nb, dtype=torch.int64, device=self.device)
                 self._gather(self.geo, 1, 2 * HW, zero, nb, x.view(nb, -1)[:, HW:], 3 * HW)
             yield {"x": x, "y": y, "mask": mask, "params": params, "idx": self._indices[pos]}
@@ -488,10 +532,18 @@ class ResidentLoader:
 
 def make_loaders(npz_path, inputs_mode="params", batch_size=16, split=0.85, seed=42,
                  device="cuda" if torch.cuda.is_available() else "cpu", y_key="Te", y_keys=None, norm_fit_batch=16,
-                 geom_h5=None, norms_by_name=None, num_workers=0, param_transform=None, resident=None):
+                 geom_h5=None, norms_by_name=None, num_workers=0, param_transform=None, resident=None, rank=None,
+                 world=None):
     """Reference: solpex/data.py:467-572.  Returns the same 8-tuple.  `resident` (extra): True = the two loaders are
     `ResidentLoader`s (dataset held and normalised in HBM, batches gathered on the device); None = automatically when
-    `device` is a GPU and one is present; False = the reference's host DataLoaders."""
+    `device` is a GPU and one is present; False = the reference's host DataLoaders.
+    `rank` / `world` (extra; default: the torch.distributed group's): under data parallelism `batch_size` is the per-rank
+    batch and every rank iterates its own share of each global batch -- same number of batches on every rank (resident
+    loaders pad a short last batch with an empty-mask sample; host loaders use torch's DistributedSampler, which pads by
+    wrapping around: call `loader.sampler.set_epoch(epoch)` for a fresh shuffle per epoch)."""
+    from . import dist as sxdist
+    rank = sxdist.rank() if rank is None else int(rank)
+    world = sxdist.world_size() if world is None else int(world)
     geom = geom_h5 if inputs_mode != "autoencoder" else None
     kw = dict(geom_h5=geom, inputs=inputs_mode, y_key=y_key, y_keys=y_keys, param_transform=param_transform)
     raw_all = SOLPSDataset(npz_path, normalizer=None, **kw)
@@ -521,8 +573,14 @@ def make_loaders(npz_path, inputs_mode="params", batch_size=16, split=0.85, seed
     if resident is None:
         resident = pin and torch.cuda.is_available()
     if resident:
-        train_loader = ResidentLoader(train_set, batch_size, True, device)
-        val_loader = ResidentLoader(val_set, batch_size, False, device)
+        train_loader = ResidentLoader(train_set, batch_size, True, device, rank=rank, world=world)
+        val_loader = ResidentLoader(val_set, batch_size, False, device, rank=rank, world=world)
+    elif world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        s_tr = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+        s_va = DistributedSampler(val_set, num_replicas=world, rank=rank, shuffle=False)
+        train_loader = DataLoader(train_set, batch_size=batch_size, sampler=s_tr, **extra)
+        val_loader = DataLoader(val_set, batch_size=batch_size, sampler=s_va, **extra)
     else:
         train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, **extra)
         val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, **extra)

@@ -36,8 +36,15 @@ def _group_ready():
     return dist.is_available() and dist.is_initialized()
 
 
+def _forced():
+    # SX_DP_FORCE=1: run the data-parallel protocol (denominator all-reduce, bucketed asynchronous gradient all-reduces, split
+    # encoder backward) even in a group of ONE rank.  A single-rank all-reduce is a valid RCCL collective, so a one-GPU box
+    # exercises the real ProcessGroupNCCL path: Work handles, RCCL's own stream, wait() ordering (tests/test_gpu_dist.py).
+    return os.environ.get("SX_DP_FORCE", "0") not in ("", "0")
+
+
 def is_active():
-    return not _LOCAL and _group_ready() and dist.get_world_size() > 1
+    return not _LOCAL and _group_ready() and (dist.get_world_size() > 1 or _forced())
 
 
 def world_size():
@@ -88,6 +95,34 @@ def all_reduce_sum(t, async_op=False):
         return _Done() if async_op else t
     h = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
     return h if async_op else t
+
+
+def broadcast0(t, device=None):
+    """Rank 0's value of a small host tensor on every rank (returned on the host)."""
+    if not is_active():
+        return t
+    if dist.get_backend() == "nccl":
+        d = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(d, src=0)
+        return d.cpu()
+    c = t.clone()
+    dist.broadcast(c, src=0)
+    return c
+
+
+def check_equal_across_ranks(value, what):
+    """Raise on every rank when an integer that must agree (e.g. batches per epoch) differs between ranks: unequal loop
+    lengths would otherwise hang in the first all-reduce one rank never reaches."""
+    if not is_active():
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    lo = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if int(lo) != int(hi):
+        raise RuntimeError(f"data parallel: {what} differs between ranks ({int(lo)}..{int(hi)}); shard the data with "
+                           "make_loaders(rank=, world=) / ResidentLoader.shard() so that every rank runs the same number of steps")
 
 
 def shard_range(n, r=None, w=None):

@@ -241,6 +241,7 @@ class UNet(nn.Module):
         self._enc_idx = [i for i, m in enumerate(mask) if m]
         self._dec_idx = [i for i, m in enumerate(mask) if not m]
         self._wcache = {}
+        self._wgen = 0
         if in_ch == base:
             raise ValueError("UNet (HIP): in_ch == base makes the first shortcut an Identity, which the fused "
                              "block kernels do not cover")
@@ -266,7 +267,8 @@ class UNet(nn.Module):
         params = self._ordered_params()
         # Packed (MFMA-layout) weights are cached per dtype/device and rebuilt when a parameter's
         # storage or version counter changed; in training mode they are rebuilt every forward.
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        # `_wgen` counts updates made through raw pointers (TrainEngine's AdamW kernel), which bump no version counter.
+        key = (self._wgen,) + tuple((p.data_ptr(), p._version) for p in params)
         ckey = (dtype, str(device))
         ent = self._wcache.get(ckey)
         sess = UNetSession(self._cfg, B, H, W, dtype, use_film, device, wpack=None if ent is None else ent[1])

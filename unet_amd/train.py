@@ -86,6 +86,7 @@ class TrainEngine:
         bot = [names[i] for i in model._enc_idx if botw(names[i])]
         enc = [names[i] for i in model._dec_idx if late(names[i])] + [names[i] for i in model._enc_idx if not botw(names[i])]
         self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + bot + enc)
+        model._wgen += 1
         self.n_dec = self.slots[(bot + enc)[0]][0] if (bot + enc) else self.flat_p.numel()
         self.n_bot = self.slots[enc[0]][0] if enc else self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
@@ -108,6 +109,7 @@ class TrainEngine:
         self.log = torch.zeros(4096, 4, dtype=torch.float32, device=self.device)
         self.nlog = 0
         self.world = sxdist.world_size()
+        self.dp = sxdist.is_active()          # world > 1 (or SX_DP_FORCE with a one-rank group)
 
     # ------------------------------------------------------------------ sessions
     def _session(self, B, H, W, use_film):
@@ -153,7 +155,7 @@ class TrainEngine:
         m = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.float().contiguous()
         loss_prepare(bufs, B, Cc, H, W, m, self.w_map, o["multiscale"], o["grad_ds"], float(lam_grad))
         px_local, handle = None, None
-        if self.world > 1:
+        if self.dp:
             px_local = bufs.den[0].clone()
             handle = sxdist.all_reduce_sum(bufs.den, async_op=True)        # batch-global denominators
         return m, px_local, handle
@@ -199,10 +201,10 @@ class TrainEngine:
         sess.decode_backward(fp, drop_table, flags)
         h_dec = None
         closing = step_now and (self.accum + 1 >= max(int(grad_accum_steps), 1))
-        if self.world > 1 and closing:
+        if self.dp and closing:
             h_dec = sxdist.all_reduce_sum(self.flat_g[:self.n_dec], async_op=True)
         h_bot = None
-        if self.world > 1 and closing and self.n_bot > self.n_dec and not os.environ.get("SX_DP_NO_SPLIT"):
+        if self.dp and closing and self.n_bot > self.n_dec and not os.environ.get("SX_DP_NO_SPLIT"):
             sess.encode_backward(fp, flags | L.SX_BWD_ONLY_BOTTLENECK)
             h_bot = sxdist.all_reduce_sum(self.flat_g[self.n_dec:self.n_bot], async_op=True)
             sess.encode_backward(fp, flags | L.SX_BWD_AFTER_BOTTLENECK)
@@ -210,7 +212,7 @@ class TrainEngine:
             sess.encode_backward(fp, flags)
         self.accum += 1
         if closing:
-            if self.world > 1:
+            if self.dp:
                 h_enc = sxdist.all_reduce_sum(self.flat_g[(self.n_bot if h_bot is not None else self.n_dec):], async_op=True)
                 h_dec.wait()
                 if h_bot is not None:
@@ -234,11 +236,12 @@ class TrainEngine:
                                   1.0, L.ptr(self.gnorm) if use_clip else None, L.ptr(nxt) if use_clip else None,
                                   L.stream_ptr()), "sx_adamw_step")
         self.accum = 0
+        self.model._wgen += 1          # the kernel wrote the parameters through raw pointers: packed-weight caches are stale
 
     def flush(self, lr=None):
         """Step with whatever gradients are pending (epoch ended mid-accumulation, train.py:235-242)."""
         if self.accum > 0:
-            if self.world > 1:
+            if self.dp:
                 sxdist.all_reduce_sum(self.flat_g)
             self.optimizer_step(lr)
 
@@ -275,7 +278,7 @@ class TrainEngine:
         self.nlog = 0
         vals = torch.tensor([float((rows[:, 0] * rows[:, 2]).sum()), float(rows[:, 1].sum()), float(rows[:, 3].sum())],
                             dtype=torch.float64)
-        if self.world > 1:
+        if self.dp:
             # rows[:,0] is this rank's share of the global loss and rows[:,2] the GLOBAL px: SUM-reducible
             v = vals.to(self.device)
             sxdist.all_reduce_sum(v)
@@ -391,6 +394,14 @@ def train_unet(
         opt.load_state_dict(ckpt_resume["opt"])
         engine.import_opt_state(opt)
 
+    if engine.dp:
+        # every rank must run the same number of steps (each step all-reduces); resident loaders built before the process
+        # group existed are re-sharded here, anything else is only checked
+        for ld in (train_loader, val_loader):
+            if hasattr(ld, "shard") and getattr(ld, "world", 1) != sxdist.world_size():
+                ld.shard(sxdist.rank(), sxdist.world_size())
+        sxdist.check_equal_across_ranks(len(train_loader), "the number of training batches per epoch")
+        sxdist.check_equal_across_ranks(len(val_loader), "the number of validation batches per epoch")
     history = {"tr_mse": [], "tr_maeN": [], "va_mse": [], "va_maeN": [], "va_mae_eV": [], "va_rmse_eV": [], "lr": []}
     rank0 = sxdist.rank() == 0
     no_improve = 0
@@ -419,7 +430,7 @@ def train_unet(
             params = b["params"].to(device, non_blocking=non_blocking) if P > 0 else None
             engine.eval_step(x, y, m, params, lam_grad=lam_grad_epoch, norm=norm, err_acc=err_acc)
         v_loss, v_abs, v_px, _ = engine.read_epoch()
-        if engine.world > 1:
+        if engine.dp:
             sxdist.all_reduce_sum(err_acc)
         ev_abs, ev_sq, _ = err_acc.tolist()
         va_loss, va_maeN = v_loss / max(v_px, 1.0), v_abs / max(v_px, 1.0)
