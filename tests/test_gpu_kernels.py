@@ -248,18 +248,13 @@ def test_conv_wgrad(L, dtype, mode, B, H, W, Cin, Cout):
     assert rel_err(dw.cpu() - 1.0, ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("tgk", ["", "0", "1", "2"])
 @pytest.mark.parametrize("mode,B,H,W,Cin,Cout", [
     # persistent bf16 tier (wgrad_ws.hip): one shape per (a fragments, b fragments, tile width) family
     (0, 3, 24, 32, 32, 32), (0, 2, 16, 16, 64, 64), (0, 5, 13, 20, 8, 32), (0, 2, 16, 48, 16, 16), (0, 1, 32, 16, 128, 64),
     (0, 2, 40, 16, 64, 128), (0, 2, 16, 8, 64, 64), (0, 3, 12, 9, 128, 32), (0, 1, 16, 16, 256, 128), (0, 2, 8, 8, 256, 256),
     (1, 3, 24, 32, 32, 32), (1, 2, 16, 16, 64, 8), (1, 2, 20, 18, 128, 64), (1, 2, 16, 8, 64, 32), (1, 2, 9, 17, 32, 128)])
-def test_conv_wgrad_persistent_bf16(L, monkeypatch, tgk, mode, B, H, W, Cin, Cout):
-    """bf16 weight gradient on channel slices of wider buffers (ld > C), every tap-group split of the block grid."""
-    if tgk:
-        monkeypatch.setenv("SX_WG_TGK", tgk)
-    else:
-        monkeypatch.delenv("SX_WG_TGK", raising=False)
+def test_conv_wgrad_persistent_bf16(L, mode, B, H, W, Cin, Cout):
+    """bf16 weight gradient on channel slices of wider buffers (ld > C)."""
     dtype = 1
     g = torch.Generator().manual_seed(H * 7 + Cin + mode)
     k = 3 if mode == 0 else 1

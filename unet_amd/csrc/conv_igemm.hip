@@ -177,13 +177,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (smem < stat_bytes) smem = stat_bytes;
   if (smem > 160 * 1024) { set_error("conv tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
   auto kern = conv_igemm_kernel<T, MI, NI, WM, WN>;
-  static size_t configured = 0;   // monotone max; a benign race re-sets the same attribute
-  if (smem > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv)");
-    configured = 160 * 1024;
-  }
+  static std::atomic<unsigned long long> done{0};
+  SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv)"));
   dim3 grid(a.tiles_x * a.tiles_y * a.B, cdiv(a.RTot, BMC));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   SX_LAUNCH_CHECK("conv_igemm");

@@ -322,13 +322,8 @@ static int launch_wgrad(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
   const size_t smem = (size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW;
   if (smem > 160 * 1024) { set_error("wgrad tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
   auto kern = wgrad_kernel<T, MI, ITEMS>;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad)");
-    configured = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(wgrad)"));
   hipLaunchKernelGGL(kern, dim3(p.a_tiles, p.b_tiles, p.nsplit), dim3(256), smem, st, a);
   SX_LAUNCH_CHECK("wgrad");
   return SX_OK;
@@ -363,7 +358,7 @@ extern "C" int64_t sx_conv_wgrad_workspace_bytes(int mode, int B, int H, int W, 
 
 namespace sx {
 int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
-                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st) {
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer) {
   SX_REQUIRE(P && Q && slab && desc, "sx_conv_wgrad: null pointer");
   SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_wgrad: bad dtype %d", dtype);
   const int EPL = dtype == SX_BF16 ? 8 : 4;
@@ -381,8 +376,14 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
     const int64_t need = wgrad_ws_slab_bytes(mode, B, H, W, Ca, Cb);
     if (need > 0) {
       SX_REQUIRE(need <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %lld)", (long long)slab_bytes, (long long)need);
-      const int rc = wgrad_ws_try(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, (float*)slab, desc, st);
-      if (rc <= 0) return rc;
+      if (defer) {          // the caller batches persistent-tier problems into one launch (wgrad_ws_launch)
+        const int rc = wgrad_ws_prepare(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, (float*)slab, desc, defer);
+        if (rc == 0) return WG_DEFERRED;
+        if (rc < 0) return rc;
+      } else {
+        const int rc = wgrad_ws_try(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, (float*)slab, desc, st);
+        if (rc <= 0) return rc;
+      }
     }
   }
   WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a);
@@ -408,7 +409,7 @@ extern "C" int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, i
   SX_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "sx_conv_wgrad: bad output channel counts");
   WgReduceDesc d;
   memset(&d, 0, sizeof(d));
-  SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, workspace, workspace_bytes, &d, (hipStream_t)stream));
+  SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, workspace, workspace_bytes, &d, (hipStream_t)stream, nullptr));
   d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = accumulate;
   return wgrad_reduce_multi(&d, 1, (hipStream_t)stream);
 }

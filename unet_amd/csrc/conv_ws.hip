@@ -359,21 +359,16 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int NBUF = 4;                                       // three stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * 2 * sizeof(float);
   auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL, VAR>;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_ws)");
-    configured = true;
-  }
+  static std::atomic<unsigned long long> done{0};
+  SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_ws)"));
   a.TH = TH; a.TW = TW;
-  if (WS_DBG) a.stamps = getenv("SX_WS_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WS_STAMPS"), nullptr, 0) : nullptr;
+  if (WS_DBG) a.stamps = getenv("SX_WS_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WS_STAMPS"), nullptr, 0) : nullptr;   // diagnostic build only
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
   const int ntiles = a.B * a.tiles_x * a.tiles_y;
   const int gy = cdiv(a.RTot, BMC);
   // persistent grid: about one block per CU (registers allow one wave per SIMD); light variants get two
-  int per_cu = 1;
-  if (const char* e = getenv("SX_WS_PER_CU")) per_cu = atoi(e);     // tuning knob
+  static const int per_cu = std::max(1, env_int("SX_WS_PER_CU", 1));     // tuning knob, read once per process
   int gx = std::max(1, std::min(ntiles, (256 * per_cu) / gy));
   gx = cdiv(ntiles, cdiv(ntiles, gx));       // contiguous tile ranges: no empty trailing blocks
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, a);

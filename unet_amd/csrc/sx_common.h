@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 #include "../../include/solpex_hip.h"
 
@@ -145,6 +146,12 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
   }
   __syncthreads();
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) once per (kernel, device): `done` is a per-kernel bit mask of
+// device ordinals (a function-local static at the call site); racing first calls are harmless (the call is idempotent)
+int ensure_max_lds(const void* kern, std::atomic<unsigned long long>& done, const char* what);
+// integer tuning knob from the environment (callers keep the result in a function-local static: read once per process)
+int env_int(const char* name, int dflt);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

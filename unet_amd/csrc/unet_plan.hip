@@ -14,6 +14,7 @@
 #include "norm_act.h"
 #include "conv_common.h"
 #include <vector>
+#include <algorithm>
 
 namespace sx {
 
@@ -241,70 +242,26 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   return film_backward(fa, wg, st);
 }
 
-// ---------------------------------------------------------------- side stream
-// Most launches of this network run 5-30 us on a 256-CU chip: launch ramp, first-touch latency and the store tail
-// are a large part of every kernel.  Work that is off the critical path (weight gradients, shortcut convolutions)
-// CAN be issued on a second stream to fill those bubbles (SX_SIDE=1|2|3); every entry point joins before it returns,
-// so callers still see single-stream semantics.  MEASURED on MI355X (cfg A, batch 64): 3.34 ms/step with either
-// use of the side stream against 3.23 ms without -- the persistent kernels own every CU while they run and the
-// cross-queue event waits cost more than the overlap returns -- so it is OFF by default.
-struct Side {
-  hipStream_t st = nullptr;
-  hipEvent_t ev[32];
-  unsigned next = 0;
-  bool ok = false;
-};
-enum { SIDE_WGRAD = 1, SIDE_SHORTCUT = 2, SIDE_TAIL = 4 };
-static Side* side_get(int what) {
-  static Side sides[16];
-  static const int enabled = getenv("SX_SIDE") ? atoi(getenv("SX_SIDE")) : 0;
-  if (!(enabled & what)) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  Side& s = sides[dev];
-  if (!s.ok) {
-    if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    for (auto& e : s.ev)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    s.ok = true;
-  }
-  return &s;
-}
-// `to` waits for everything enqueued on `from` so far
-static int stream_after(Side* s, hipStream_t from, hipStream_t to) {
-  if (!s || from == to) return SX_OK;
-  hipEvent_t e = s->ev[s->next++ % 32];
-  hipError_t rc = hipEventRecord(e, from);
-  if (rc != hipSuccess) return hip_fail(rc, "hipEventRecord");
-  rc = hipStreamWaitEvent(to, e, 0);
-  if (rc != hipSuccess) return hip_fail(rc, "hipStreamWaitEvent");
-  return SX_OK;
-}
-
 // ---------------------------------------------------------------- weight-gradient queue
-// Every layer's split-K kernel writes its own slab; ONE fused launch reduces them all at the end of a backward half
-// (25 tiny reduce launches per step were ~8 % of the step).
+// The weight gradients of a backward half are independent of its data-gradient chain: every layer's split-K problem is
+// only DESCRIBED when the chain passes it (its operands stay untouched in the workspace: nothing is aliased), and at the end of
+// the half ONE launch runs all of them (wgrad_ws_launch: block ranges per problem, longest first) and ONE launch reduces all
+// slabs.  23 weight-gradient launches per step of 7-45 us each -- ~8 us of ramp, first touch and store tail apiece -- become 2.
 struct WgQueue {
   char* base; int64_t cap, used; int dtype, B, acc;
-  hipStream_t main, st;          // st: where the weight-gradient kernels run (the side stream if there is one)
-  Side* side;
-  std::vector<WgReduceDesc> pending;
-  std::vector<GnGradDesc> gn;      // GroupNorm affine gradients, reduced over the batch in one launch at the end
-  WgQueue(const Plan& p, void* ws, int acc_, hipStream_t main_)
-      : base((char*)ws + p.wg_ws), cap(p.wg_ws_bytes), used(0), dtype(p.d.dtype), B(p.d.B), acc(acc_), main(main_) {
-    side = side_get(SIDE_WGRAD);
-    st = side ? side->st : main_;
-  }
-  // what `main` has produced so far becomes visible to the weight-gradient stream
-  int fork() { return stream_after(side, main, st); }
-  // reduce everything pending and make `main` wait for it
+  hipStream_t st;
+  std::vector<WgWsLaunch> launches;   // persistent-tier problems not launched yet
+  std::vector<WgReduceDesc> pending;  // slabs not reduced yet
+  std::vector<GnGradDesc> gn;         // GroupNorm affine gradients, reduced over the batch in one launch at the end
+  WgQueue(const Plan& p, void* ws, int acc_, hipStream_t st_)
+      : base((char*)ws + p.wg_ws), cap(p.wg_ws_bytes), used(0), dtype(p.d.dtype), B(p.d.B), acc(acc_), st(st_) {}
+  // launch and reduce everything pending, then the small per-channel reductions
   int finish() {
     SX_TRY(flush());
-    SX_TRY(stream_after(side, st, main));
-    return finish_gn(main);
+    return finish_gn();
   }
-  int finish_gn(hipStream_t on) {
-    if (!gn.empty()) SX_TRY(gn_param_grad_multi(gn.data(), (int)gn.size(), B, acc, on));
+  int finish_gn() {
+    if (!gn.empty()) SX_TRY(gn_param_grad_multi(gn.data(), (int)gn.size(), B, acc, st));
     gn.clear();
     return SX_OK;
   }
@@ -320,12 +277,23 @@ struct WgQueue {
     gn.push_back(d);
   }
   int flush() {
+    if (!launches.empty()) {
+      // longest problems first: the short ones fill the tail (cost ~ operand bytes x taps)
+      std::stable_sort(launches.begin(), launches.end(), [](const WgWsLaunch& x, const WgWsLaunch& y) {
+        auto cost = [](const WgWsLaunch& l) {
+          return (double)l.a.B * l.a.H * l.a.W * (l.a.CaPad + l.a.CbPad) * (l.variant >> 8 & 15);
+        };
+        return cost(x) > cost(y);
+      });
+      SX_TRY(wgrad_ws_launch(launches.data(), (int)launches.size(), st));
+      launches.clear();
+    }
     if (!pending.empty()) SX_TRY(wgrad_reduce_multi(pending.data(), (int)pending.size(), st));
     pending.clear();
     used = 0;
     return SX_OK;
   }
-  // conv1 (3x3) and the 1x1 shortcut of a 32-channel DoubleConv in ONE launch: P = the [dY1 | dR] buffer, 64 channels = one
+  // conv1 (3x3) and the 1x1 shortcut of a 32-channel DoubleConv in ONE problem: P = the [dY1 | dR] buffer, 64 channels = one
   // full 128-byte line per pixel (each half on its own is half-line reads of the same lines), the shortcut rows multiply the
   // centre tap only; two descriptors reduce the two row ranges of the slab.  Returns 1 when the shape is not covered.
   int add_dual(int H, int W, int C, int Cb, int Cb_out, const void* P, const void* Q, int q_ld, float* dw3, float* dw1) {
@@ -337,8 +305,10 @@ struct WgQueue {
     if (used + need > cap) SX_TRY(flush());
     WgReduceDesc d;
     memset(&d, 0, sizeof(d));
-    const int rc = wgrad_ws_try(SX_CONV3, B, H, W, 2 * C, Cb, P, 2 * C, Q, q_ld, H, W, (float*)(base + used), &d, st, 1);
+    WgWsLaunch l;
+    const int rc = wgrad_ws_prepare(SX_CONV3, B, H, W, 2 * C, Cb, P, 2 * C, Q, q_ld, H, W, (float*)(base + used), &d, &l, 1);
     if (rc != 0) return rc;
+    launches.push_back(l);
     d.Ca = C; d.Cb = Cb_out; d.accumulate = acc;
     WgReduceDesc d3 = d, d1 = d;
     d3.out = dw3; d3.a16_lo = 0; d3.a16_n = C / 16; d3.tap_lo = 0; d3.tap_n = 9;
@@ -354,7 +324,10 @@ struct WgQueue {
     if (used + need > cap) SX_TRY(flush());
     WgReduceDesc d;
     memset(&d, 0, sizeof(d));
-    SX_TRY(wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, base + used, cap - used, &d, st));
+    WgWsLaunch l;
+    const int rc = wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, base + used, cap - used, &d, st, &l);
+    if (rc == WG_DEFERRED) launches.push_back(l);
+    else SX_TRY(rc);
     d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = acc;
     pending.push_back(d);
     used += need;
@@ -369,24 +342,12 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const float* g1 = params[b.pidx + 1]; const float* be1 = params[b.pidx + 2];
   const float* g2 = params[b.pidx + 4]; const float* be2 = params[b.pidx + 5];
-  // conv1 (+ GroupNorm statistics) and the 1x1 shortcut in one pass over the block input; with SX_SIDE=2 the shortcut
-  // runs as its own launch on the side stream instead
-  Side* side = side_get(SIDE_SHORTCUT);
-  hipStream_t ss = side ? side->st : st;
-  if (side) {
-    SX_TRY(stream_after(side, st, ss));
-    SX_TRY(sx_conv_forward(dt, SX_CONV1, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.wsf), nullptr,
-                           at(ws, b.S), b.C, b.H, b.W, 0, nullptr, 0, ss));
-    SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, b.H, b.W, at(wpack, b.w1f), nullptr,
-                           at(ws, b.Y1), b.C, b.H, b.W, 0, (float*)at(ws, b.st1), b.G, st));
-  } else {
-    SX_TRY(sx_conv3_shortcut_forward(dt, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, at(wpack, b.w1f), at(wpack, b.wsf),
-                                     at(ws, b.Y1), b.C, (float*)at(ws, b.st1), b.G, at(ws, b.S), b.C, st));
-  }
+  // conv1 (+ GroupNorm statistics) and the 1x1 shortcut in one pass over the block input
+  SX_TRY(sx_conv3_shortcut_forward(dt, B, b.H, b.W, b.Cin, b.C, at(ws, b.in), b.in_ld, at(wpack, b.w1f), at(wpack, b.wsf),
+                                   at(ws, b.Y1), b.C, (float*)at(ws, b.st1), b.G, at(ws, b.S), b.C, st));
   SX_TRY(sx_gn_silu_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1, at(ws, b.A1), b.C, st));
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.A1), b.C, b.H, b.W, at(wpack, b.w2f), nullptr,
                          at(ws, b.Y2), b.C, b.H, b.W, 0, (float*)at(ws, b.st2), b.G, st));
-  SX_TRY(stream_after(side, ss, st));
   const bool keep_r = film || drop;
   if (pool && !(b.H & 1) && !(b.W & 1)) {      // encoder block: its max-pooled output in the same pass
     *pooled = true;
@@ -427,18 +388,16 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   const void* dR = at(ws, b.dR);
   const int dr_ld = 2 * b.C;
   if (wg) {
-    SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
   }
   SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w2d), nullptr,
                          at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
-  // through SiLU / GN1 (its own buffer: the weight-gradient stream may still be reading dY)
+  // through SiLU / GN1 (its own buffer: the deferred weight-gradient launch still reads dY)
   SX_TRY(sx_gn_silu_backward(dt, 0, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
                              at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), 2 * b.C,
                              nullptr, 0, nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
   if (wg) {
-    SX_TRY(wq.fork());
     const int rc = wq.add_dual(b.H, b.W, b.C, b.Cin, b.Cin_real, at(ws, b.dY1), at(ws, b.in), b.in_ld, grads[b.pidx + 0], grads[b.pidx + 6]);
     if (rc < 0) return rc;
     if (rc == 1) {
@@ -629,7 +588,6 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   // head
   const BlockBuf& last = p.blk[2 * D];
   if (wg) {
-    SX_TRY(wq.fork());
     SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
                   at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
     SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), stream));
@@ -650,8 +608,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
       if (!ride)
         SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), stream));
       wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[l]);
-      SX_TRY(wq.fork());
-      SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
+        SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
                     at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]]));
     }
     // gradient w.r.t. the transposed conv's input = d_out of the previous block
@@ -697,8 +654,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
   if (!after_bot) SX_TRY(block_backward(p, D, params, grads, wpack, ws, film, nullptr, true, flags, wq, st));
   if (only_bot) {
     wq.gn.clear();
-    SX_TRY(wq.flush());
-    return stream_after(wq.side, wq.st, st);
+    return wq.flush();
   }
   if (after_bot && wg) {
     const BlockBuf& b = p.blk[D];
@@ -722,21 +678,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch);
     for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
   }
-  // The tail of a step's backward is three independent pieces: the slab reduction (bandwidth, thousands of blocks), the
-  // GroupNorm-affine / bias reductions and the FiLM generators' backward (latency chains on a few dozen blocks, ~60 us in
-  // a row).  SX_SIDE=4 runs the small ones on a second stream next to the reduction; the entry point joins before it
-  // returns.  MEASURED (three A/B pairs, same box): 2.125 ms/step with it, 2.089 without -- the two cross-queue event waits
-  // cost more than the ~45 us of overlap: OFF by default, like the other side-stream uses.
-  Side* tail = side_get(SIDE_TAIL);
   const int ngen = (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1;
-  if (tail && wg && tail->st != st) {
-    SX_TRY(stream_after(tail, st, tail->st));
-    SX_TRY(wq.finish_gn(tail->st));
-    if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, tail->st));
-    SX_TRY(wq.finish());
-    SX_TRY(stream_after(tail, tail->st, st));
-    return SX_OK;
-  }
   SX_TRY(wq.finish());
   if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, st));
   return SX_OK;

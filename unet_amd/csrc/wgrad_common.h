@@ -22,8 +22,29 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st);
 
 // Launches the split-K kernel of one layer into `slab` and fills `desc` (slab, nsplit, ntaps, CaPad, CbPad).
 // The caller completes desc (out, Ca, Cb, accumulate) and reduces now or later.
+// `defer` (nullable): a problem the persistent bf16 tier covers is not launched but described in *defer, and the call
+// returns WG_DEFERRED; the caller launches a batch of them with wgrad_ws_launch (before reducing).
+struct WgWsLaunch;
+static constexpr int WG_DEFERRED = 2;
 int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
-                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st);
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer);
+
+struct WgWsArgs {
+  const bf16* P; const bf16* Q; float* slab;
+  int B, H, W, p_ld, q_ld;
+  int Hq, Wq;                   // Q image dims (= H, W except for the transposed conv: >= 2H, 2W)
+  int Ca, Cb, CaPad, CbPad;
+  int a_tiles, b_tiles, tg_count, R, S;
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int dbg;
+  unsigned long long* stamps;   // diagnostic build only
+};
+
+// A prepared problem of the persistent bf16 tier: kernel arguments, instantiation code, grid and dynamic LDS.
+struct WgWsLaunch { WgWsArgs a; int variant, blocks, smem; };
+int wgrad_ws_prepare(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual = 0);
+int wgrad_ws_launch(const WgWsLaunch* l, int n, hipStream_t st);
 
 // Persistent bf16 tier.  slab bytes it needs (0 = shape not covered) / launch (0 = launched, 1 = not covered, <0 error).
 int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb);

@@ -19,20 +19,11 @@
 //     than a plain split-K over every CU (slab traffic, not operand traffic, dominated the first version).
 #include "wgrad_common.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace sx {
 
-struct WgWsArgs {
-  const bf16* P; const bf16* Q; float* slab;
-  int B, H, W, p_ld, q_ld;
-  int Hq, Wq;                   // Q image dims (= H, W except for the transposed conv: >= 2H, 2W)
-  int Ca, Cb, CaPad, CbPad;
-  int a_tiles, b_tiles, tg_count, R, S;
-  int tiles_x, tiles_y, ntiles, tiles_per_split;
-  int dbg;
-  unsigned long long* stamps;   // diagnostic build only
-};
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -95,7 +86,7 @@ struct WgTilePos {
 static constexpr bool DBG = false;  // SX_WG_DBG ablation switches (bit 0: no MFMA loop, bit 1: no operand traffic)
 
 template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF, bool DUAL = false>
-__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
+__device__ __forceinline__ void wgrad_ws_body(const WgWsArgs& a, const int block_id) {
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr bool CT = TAPS == 4;                       // transposed conv: four parity sub-images of Q, no halo
   static_assert(!CT || (TGH == 1 && TGW == 1), "transposed conv: taps are sub-images, not shifts");
@@ -124,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   const int n = lane & 15, g = lane >> 4, q4 = n >> 2, p4 = n & 3;
 
   // ---- which part of the problem: partners (same pixel range, different r) are 8 block ids apart = same XCD
-  const int id = blockIdx.x, xcd = id & 7, wq = id >> 3;
+  const int id = block_id, xcd = id & 7, wq = id >> 3;
   const int split = (wq / a.R) * 8 + xcd;
   int r = wq % a.R;
   if (split >= a.S) return;
@@ -321,22 +312,92 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
   }
   if (DBG && a.stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    unsigned long long* o = a.stamps + (size_t)block_id * 8;
     o[0] = t_entry; o[1] = t_setup; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
     o[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, int NBUF, bool DUAL = false>
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgWsArgs a) {
+  wgrad_ws_body<TAPS, TGH, TGW, MI, NBF, TWL, NBUF, DUAL>(a, (int)blockIdx.x);
+}
+
+// ---- every weight gradient of a backward half in ONE launch.  The layers' split-K problems are independent of each other
+// and of the data-gradient chain, and each of them alone is a 7-45 us launch of which ~8 us are ramp, first touch and slab
+// store tail: queued behind one another in a single grid (block ranges per problem, every range a multiple of 8 blocks so
+// that "block id & 7 = XCD" holds inside each), the tail of one problem runs under the head of the next and the
+// per-dispatch cost is paid once.  A block looks up its problem and jumps to that problem's instantiation of the body.
+template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL>
+struct WgGeom {
+  static constexpr int TW = 1 << TWL, TH = 128 / TW;
+  static constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
+  static constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
+  static constexpr int NPT = (128 * MI * 2) / 256 + ((TAPS == 4 ? 4 : 1) * LH * QPITCH * NBF * 2 + 255) / 256;
+  static constexpr int NBUF = NPT * 4096 * 4 <= 160 * 1024 ? 4 : 3;
+  static constexpr int SMEM = NBUF * NPT * 4096;
+};
+
+// variant code = DUAL << 12 | TAPS << 8 | MI << 5 | NBF << 2 | (TWL - 3)   (all-taps blocks only: TGH x TGW = the whole stencil)
+#define SX_WG_VARIANTS(X)                                                                                     \
+  X(9, 3, 3, 1, 1, 4, false) X(9, 3, 3, 1, 2, 4, false) X(9, 3, 3, 1, 4, 4, false)                             \
+  X(9, 3, 3, 2, 1, 4, false) X(9, 3, 3, 2, 2, 4, false) X(9, 3, 3, 2, 4, 4, false)                             \
+  X(9, 3, 3, 4, 1, 4, false) X(9, 3, 3, 4, 2, 4, false) X(9, 3, 3, 4, 4, 4, false)                             \
+  X(9, 3, 3, 4, 4, 3, false) X(9, 3, 3, 4, 2, 3, false) X(9, 3, 3, 2, 4, 3, false) X(9, 3, 3, 2, 2, 3, false) \
+  X(1, 1, 1, 1, 1, 4, false) X(1, 1, 1, 1, 2, 4, false) X(1, 1, 1, 1, 4, 4, false)                             \
+  X(1, 1, 1, 2, 1, 4, false) X(1, 1, 1, 2, 2, 4, false) X(1, 1, 1, 2, 4, 4, false)                             \
+  X(1, 1, 1, 4, 1, 4, false) X(1, 1, 1, 4, 2, 4, false) X(1, 1, 1, 4, 4, 4, false)                             \
+  X(1, 1, 1, 4, 4, 3, false) X(1, 1, 1, 4, 2, 3, false) X(1, 1, 1, 2, 4, 3, false) X(1, 1, 1, 2, 2, 3, false) \
+  X(4, 1, 1, 4, 2, 4, false) X(4, 1, 1, 4, 2, 3, false)                                                       \
+  X(9, 3, 3, 4, 4, 4, true) X(9, 3, 3, 4, 1, 4, true)
+
+static constexpr int wg_variant_code(int taps, int mi, int nbf, int twl, bool dual) {
+  return (dual ? 1 << 12 : 0) | taps << 8 | mi << 5 | nbf << 2 | (twl - 3);
+}
+
+static constexpr int WG_MULTI_MAX = 16;
+struct WgWsMultiArgs {
+  WgWsArgs p[WG_MULTI_MAX];
+  int variant[WG_MULTI_MAX];
+  int blk0[WG_MULTI_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad_ws_multi_kernel(const WgWsMultiArgs) {
+  // The table is read straight from the kernel-argument segment (scalar loads at a uniform dynamic offset): indexing the
+  // by-value parameter itself made the compiler copy all 2 KB of it to scratch, per lane.
+  typedef const WgWsMultiArgs __attribute__((address_space(4))) * TablePtr;
+  TablePtr A = (TablePtr)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  const int n = A->n;
+  while (pi + 1 < n && (int)blockIdx.x >= A->blk0[pi + 1]) ++pi;
+  const int id = (int)blockIdx.x - A->blk0[pi];
+  WgWsArgs a;
+  __builtin_memcpy(&a, &A->p[pi], sizeof(a));
+  switch (A->variant[pi]) {
+#define SX_WG_BODY(taps, tgh, tgw, mi, nbf, twl, dual)                                                             \
+    case wg_variant_code(taps, mi, nbf, twl, dual):                                                                 \
+      wgrad_ws_body<taps, tgh, tgw, mi, nbf, twl, WgGeom<taps, tgh, tgw, mi, nbf, twl>::NBUF, dual>(a, id);         \
+      break;
+    SX_WG_VARIANTS(SX_WG_BODY)
+#undef SX_WG_BODY
+    default: break;
   }
 }
 
 // ------------------------------------------------------------------ host side
 struct WgWsPlan {
   bool ok;
-  int taps, tgk;          // tgk: 0 = all taps per block, 1 = one tap row, 2 = one tap
+  int taps;
   int MI, NBF, TWL;
   int a_tiles, b_tiles, tg_count, R, S;
   int tiles_x, tiles_y, ntiles, tiles_per_split;
   int CaPad, CbPad;
   int64_t slab_bytes;
 };
+
+// tuning knobs, read once per process
+static int wg_min_tiles(bool ct) { static const int v = env_int("SX_WG_MIN_TILES", 0); return v > 0 ? v : (ct ? 4 : 8); }
 
 static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
   WgWsPlan p;
@@ -361,78 +422,46 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
   const int TW = 1 << p.TWL, TH = 128 / TW;
   p.tiles_x = cdiv(W, TW); p.tiles_y = cdiv(H, TH);
   p.ntiles = B * p.tiles_x * p.tiles_y;
-  const double npix = (double)B * H * W;
-  const double out_bytes = (double)p.taps * p.CaPad * p.CbPad * 4;
-  const double flops = 2.0 * npix * p.taps * p.CaPad * p.CbPad;
-  const int force = getenv("SX_WG_TGK") ? atoi(getenv("SX_WG_TGK")) : -1;   // tuning knob
-  double best = 1e30;
-  for (int tgk = 0; tgk < (p.taps == 9 ? 3 : 1); ++tgk) {
-    if (force >= 0 && p.taps == 9 && tgk != force) continue;
-    if (force < 0 && tgk != 0) continue;      // measured: splitting the taps over blocks never paid on cfg A
-    const int tgc = tgk == 0 ? 1 : (tgk == 1 ? 3 : 9);
-    const int tgh = tgk == 0 ? (p.taps == 9 ? 3 : 1) : 1, tgw = (tgk == 2 || p.taps == 1) ? 1 : 3;
-    const int R = p.a_tiles * p.b_tiles * tgc;
-    // at least MIN_TILES tiles per block: slab traffic (S slabs written, then read by the reduction) is what small-K
-    // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
-    const int min_tiles = getenv("SX_WG_MIN_TILES") ? atoi(getenv("SX_WG_MIN_TILES")) : (ct ? 4 : 8);
-    int S = std::max(1, std::min(std::max(1, p.ntiles / min_tiles), 256 / R));
-    const int tps = cdiv(p.ntiles, S);
-    S = cdiv(p.ntiles, tps);
-    const double halo = (double)(TH + tgh - 1) * (TW + tgw - 1) / (TH * TW);
-    const double l2 = (double)R * npix * (p.MI * 32 + p.NBF * 32 * halo);
-    const double hbm = npix * (Ca + Cb) * 2;
-    const double fill = std::max(1.0, 256.0 / (S * R));
-    const double t = fill * std::max(std::max(l2 / 15e12, hbm / 5e12), flops / 1.2e15) + 2 * S * out_bytes / 4e12;
-    if (t < best) { best = t; p.tgk = tgk; p.tg_count = tgc; p.R = R; p.S = S; p.tiles_per_split = tps; }
-  }
-  p.slab_bytes = (int64_t)p.S * (int64_t)out_bytes;
+  // every block owns ALL taps of its (a tile, b tile) (splitting the taps over blocks was measured and never paid on cfg A).
+  // At least MIN_TILES tiles per block: slab traffic (S slabs written, then read by the reduction) is what small-K
+  // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
+  p.tg_count = 1;
+  p.R = p.a_tiles * p.b_tiles;
+  int S = std::max(1, std::min(std::max(1, p.ntiles / wg_min_tiles(ct)), 256 / p.R));
+  p.tiles_per_split = cdiv(p.ntiles, S);
+  p.S = cdiv(p.ntiles, p.tiles_per_split);
+  p.slab_bytes = (int64_t)p.S * p.taps * p.CaPad * p.CbPad * 4;
   p.ok = true;
   return p;
 }
 
-template <int TAPS, int TGH, int TGW, int MI, int NBF, int TWL, bool DUAL = false>
-static int launch_wgws(const WgWsArgs& a, hipStream_t st) {
-  constexpr int TW = 1 << TWL, TH = 128 / TW;
-  constexpr int LW = TW + TGW - 1, LH = TH + TGH - 1;
-  constexpr int QPITCH = NBF == 1 ? ((LW + 7) & ~7) : LW;
-  constexpr int NPT = (128 * MI * 2) / 256 + ((TAPS == 4 ? 4 : 1) * LH * QPITCH * NBF * 2 + 255) / 256;
-  constexpr int NBUF = NPT * 4096 * 4 <= 160 * 1024 ? 4 : 3;
-  const size_t smem = (size_t)NBUF * NPT * 4096;
-  auto kern = wgrad_ws_kernel<TAPS, TGH, TGW, MI, NBF, TWL, NBUF, DUAL>;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad_ws)");
-    configured = true;
+// per-variant launch facts (dynamic LDS) and the one-time function attribute, keyed by the variant code
+static int wg_variant_smem(int code) {
+  switch (code) {
+#define SX_WG_SMEM(taps, tgh, tgw, mi, nbf, twl, dual) \
+    case wg_variant_code(taps, mi, nbf, twl, dual): return WgGeom<taps, tgh, tgw, mi, nbf, twl>::SMEM;
+    SX_WG_VARIANTS(SX_WG_SMEM)
+#undef SX_WG_SMEM
   }
-  const int blocks = cdiv(a.S, 8) * 8 * a.R;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, a);
+  return -1;
+}
+
+static int launch_single(const WgWsLaunch& l, hipStream_t st) {
+  switch (l.variant) {
+#define SX_WG_LAUNCH(taps, tgh, tgw, mi, nbf, twl, dual)                                                           \
+    case wg_variant_code(taps, mi, nbf, twl, dual): {                                                                \
+      auto kern = wgrad_ws_kernel<taps, tgh, tgw, mi, nbf, twl, WgGeom<taps, tgh, tgw, mi, nbf, twl>::NBUF, dual>;   \
+      static std::atomic<unsigned long long> done{0};                                                                \
+      SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(wgrad_ws)"));            \
+      hipLaunchKernelGGL(kern, dim3(l.blocks), dim3(512), (size_t)l.smem, st, l.a);                                   \
+      break;                                                                                                         \
+    }
+    SX_WG_VARIANTS(SX_WG_LAUNCH)
+#undef SX_WG_LAUNCH
+    default: set_error("wgrad_ws: unknown variant %d", l.variant); return SX_ERR_INVALID;
+  }
   SX_LAUNCH_CHECK("wgrad_ws");
   return SX_OK;
-}
-
-template <int TAPS, int TGH, int TGW, int TWL>
-static int wgws_pick_frag(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) {
-#define SX_WG_CASE(mi, nbf) \
-  if (p.MI == mi && p.NBF == nbf) return launch_wgws<TAPS, TGH, TGW, mi, nbf, TWL>(a, st);
-  if constexpr (TWL == 4) {
-    SX_WG_CASE(1, 1) SX_WG_CASE(1, 2) SX_WG_CASE(1, 4)
-    SX_WG_CASE(2, 1) SX_WG_CASE(2, 2) SX_WG_CASE(2, 4)
-    SX_WG_CASE(4, 1) SX_WG_CASE(4, 2) SX_WG_CASE(4, 4)
-  } else {
-    SX_WG_CASE(4, 4) SX_WG_CASE(4, 2) SX_WG_CASE(2, 4) SX_WG_CASE(2, 2)
-  }
-#undef SX_WG_CASE
-  return 1;
-}
-
-template <int TWL>
-static int wgws_pick_taps(const WgWsPlan& p, const WgWsArgs& a, hipStream_t st) {
-  if (p.taps == 4) return launch_wgws<4, 1, 1, 4, 2, TWL>(a, st);
-  if (p.taps == 1) return wgws_pick_frag<1, 1, 1, TWL>(p, a, st);
-  if (p.tgk == 0) return wgws_pick_frag<9, 3, 3, TWL>(p, a, st);
-  if (p.tgk == 1) return wgws_pick_frag<9, 1, 3, TWL>(p, a, st);
-  return wgws_pick_frag<9, 1, 1, TWL>(p, a, st);
 }
 
 int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
@@ -440,24 +469,59 @@ int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
   return p.ok ? p.slab_bytes : 0;
 }
 
-int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                 float* slab, WgReduceDesc* desc, hipStream_t st, int dual) {
+// 0 = prepared (launch with wgrad_ws_launch), 1 = shape not covered
+int wgrad_ws_prepare(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual) {
   const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
   if (!p.ok) return 1;
-  if (dual && (mode != SX_CONV3 || p.MI != 4 || (p.NBF != 4 && p.NBF != 1) || p.a_tiles != 1 || p.b_tiles != 1 || p.tgk != 0 || p.TWL != 4 || Ca != 64)) return 1;
-  WgWsArgs a;
+  if (dual && (mode != SX_CONV3 || p.MI != 4 || (p.NBF != 4 && p.NBF != 1) || p.a_tiles != 1 || p.b_tiles != 1 || p.TWL != 4 || Ca != 64)) return 1;
+  WgWsArgs& a = out->a;
   memset(&a, 0, sizeof(a));
   a.P = (const bf16*)P; a.Q = (const bf16*)Q; a.slab = slab;
   a.B = B; a.H = H; a.W = W; a.p_ld = p_ld; a.q_ld = q_ld; a.Hq = Hq; a.Wq = Wq;
   a.Ca = Ca; a.Cb = Cb; a.CaPad = p.CaPad; a.CbPad = p.CbPad;
   a.a_tiles = p.a_tiles; a.b_tiles = p.b_tiles; a.tg_count = p.tg_count; a.R = p.R; a.S = p.S;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.ntiles = p.ntiles; a.tiles_per_split = p.tiles_per_split;
-  a.dbg = getenv("SX_WG_DBG") ? atoi(getenv("SX_WG_DBG")) : 0;
-  a.stamps = getenv("SX_WG_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WG_STAMPS"), nullptr, 0) : nullptr;
-  const int rc = dual ? (p.NBF == 4 ? launch_wgws<9, 3, 3, 4, 4, 4, true>(a, st) : launch_wgws<9, 3, 3, 4, 1, 4, true>(a, st)) : (p.TWL == 4 ? wgws_pick_taps<4>(p, a, st) : wgws_pick_taps<3>(p, a, st));
-  if (rc != SX_OK) return rc;
+  out->variant = wg_variant_code(p.taps, p.MI, p.NBF, p.TWL, dual != 0);
+  out->smem = wg_variant_smem(out->variant);
+  if (out->smem < 0) return 1;
+  out->blocks = cdiv(p.S, 8) * 8 * p.R;
   desc->slab = slab; desc->nsplit = p.S; desc->ntaps = p.taps; desc->CaPad = p.CaPad; desc->CbPad = p.CbPad; desc->tiled = 1;
   return SX_OK;
+}
+
+// One launch for up to WG_MULTI_MAX prepared problems (more are split over several launches); a single problem uses its
+// own instantiation.  Problems run in the order given: put the long ones first.
+int wgrad_ws_launch(const WgWsLaunch* l, int n, hipStream_t st) {
+  static const int no_multi = env_int("SX_WG_NO_MULTI", 0);        // A/B knob: one launch per problem
+  for (int i0 = 0; i0 < n;) {
+    const int m = no_multi ? 1 : std::min(WG_MULTI_MAX, n - i0);
+    if (m == 1) { SX_TRY(launch_single(l[i0], st)); ++i0; continue; }
+    WgWsMultiArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = m;
+    int blk = 0, smem = 0;
+    for (int i = 0; i < m; ++i) {
+      A.p[i] = l[i0 + i].a; A.variant[i] = l[i0 + i].variant; A.blk0[i] = blk;
+      blk += l[i0 + i].blocks;                 // a multiple of 8: block id & 7 stays the XCD inside every problem
+      smem = std::max(smem, l[i0 + i].smem);
+    }
+    A.blk0[m] = blk;
+    static std::atomic<unsigned long long> done{0};
+    SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(wgrad_ws_multi_kernel), done, "hipFuncSetAttribute(wgrad_ws_multi)"));
+    hipLaunchKernelGGL(wgrad_ws_multi_kernel, dim3(blk), dim3(512), (size_t)smem, st, A);
+    SX_LAUNCH_CHECK("wgrad_ws_multi");
+    i0 += m;
+  }
+  return SX_OK;
+}
+
+int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
+                 float* slab, WgReduceDesc* desc, hipStream_t st, int dual) {
+  WgWsLaunch l;
+  const int rc = wgrad_ws_prepare(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, slab, desc, &l, dual);
+  if (rc != 0) return rc;
+  return wgrad_ws_launch(&l, 1, st);
 }
 
 }  // namespace sx
