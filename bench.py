@@ -71,7 +71,8 @@ def conv_launches(B):
         px = 2.0 * B * h * w
         out.append(("dual", h, w, cin, c, px * cin_real * c * 10))        # conv1 + shortcut forward
         out.append(("c3", h, w, c, c, px * c * c * 9))                     # conv2 forward
-        out.append(("c3", h, w, c, c, px * c * c * 9))                     # conv2 data gradient
+        # conv2 data gradient; where the kernel covers it, with GroupNorm-1's backward sums fused (reads Y1 as well)
+        out.append(("c3" if c == 128 else "c3bs", h, w, c, c, px * c * c * 9))
         if need_dx:
             out.append(("center", h, w, c, cin, px * cin_real * c * 10))   # conv1 + shortcut data gradient
     for l in range(4):                                                     # encoders + bottleneck
@@ -126,6 +127,16 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
                 L.check(lib.sx_conv_forward(sx_dtype, 2, B, h, w, cin, cout, L.ptr(x), cin, h, w, L.ptr(wp), L.ptr(bias), L.ptr(y),
                                             2 * cout, 2 * h, 2 * w, 0, None, 0, L.stream_ptr()))
             return launch, (x, y[..., :cout], wp)
+        if kind == "c3bs":
+            x, y, y1 = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt), rnd(B, h, w, cout)
+            wp = packed(0, cout, cin)
+            stats = torch.stack([torch.zeros(B, 8, device="cuda"), torch.full((B, 8), float(h * w * cout // 8), device="cuda")], -1).contiguous()
+            ga, be, sums = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(B, cout, 4, device="cuda")
+            def launch():
+                L.check(lib.sx_conv_forward_gn_bwd_sums(sx_dtype, 0, B, h, w, cin, cout, L.ptr(x), cin, L.ptr(wp), L.ptr(y), cout, 0,
+                                                        L.ptr(y1), cout, None, 0, L.ptr(stats), 8, 1e-5, L.ptr(ga), L.ptr(be), None, None,
+                                                        L.ptr(sums), L.stream_ptr()))
+            return launch, (x, y, y1, wp)
         mode = 0 if kind == "c3" else 1
         x, y = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)
         wp = packed(mode, cout, cin)
@@ -183,7 +194,7 @@ def conv_traffic(a):
     """HBM bytes per step of the same launches from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate
     rocprofv3 --pmc runs of this file and committed under profiles/: tools/pmc_traffic.py).  Only valid for the
     configuration it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_ws_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_conv_ws_traffic.json")
     if a.batch != 64 or a.dtype != "bf16" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -221,6 +232,43 @@ def cpu_baseline(batch, steps):
         step(i + 1)
     dt = time.perf_counter() - t0
     return batch * steps / dt, dt
+
+
+def config1_gpu(dev, reps=50):
+    """BASELINE configs[0] on the GPU: forward + masked MSE (base="mse", lam_grad=0, lam_w=0), batch 8, fp32 tier."""
+    from unet_amd.losses import masked_weighted_loss
+    from unet_amd.synth import make_batch
+    model = make_model(0).to(dev).eval()
+    model.compute_dtype = torch.float32
+    bt = make_batch(8, H, W, seed=77)
+    x, y, m, p = (bt[k].to(dev) for k in ("x", "y", "mask", "params"))
+    with torch.no_grad():
+        for _ in range(5):
+            loss = masked_weighted_loss(model(x, params=p), y, m, base="mse", lam_grad=0.0, lam_w=0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = masked_weighted_loss(model(x, params=p), y, m, base="mse", lam_grad=0.0, lam_w=0.0)
+        torch.cuda.synchronize()
+    return 8 * reps / (time.perf_counter() - t0), float(loss)
+
+
+def config1_cpu(reps=20):
+    """The same workload through the CPU oracle (port of the reference's PyTorch path), fp32, on the host cores."""
+    from oracle import unet_ref, loss_ref
+    from oracle.unet_ref import UNetCfg
+    from unet_amd.synth import make_batch
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=32, P=5, film_hidden=128, depth=3)
+    sd = {k: v.detach().cpu().clone() for k, v in make_model(0).state_dict().items()}
+    bt = make_batch(8, H, W, seed=77)
+    with torch.no_grad():
+        loss = loss_ref.masked_weighted_loss(unet_ref.unet_forward(sd, cfg, bt["x"], bt["params"]), bt["y"], bt["mask"], base="mse",
+                                             lam_grad=0.0, lam_w=0.0)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = loss_ref.masked_weighted_loss(unet_ref.unet_forward(sd, cfg, bt["x"], bt["params"]), bt["y"], bt["mask"],
+                                                 base="mse", lam_grad=0.0, lam_w=0.0)
+    return 8 * reps / (time.perf_counter() - t0), float(loss)
 
 
 def main():
@@ -268,6 +316,25 @@ def main():
     loss_last = float(lt)
     value = world * a.batch * a.steps / dt
     infer = None if a.no_infer else measure_infer(model, x, p, dtype, a.steps, a.warmup, world, sync, dev)
+    dp_diag = None
+    if world > 1:
+        # diagnostic for the scaling runs: the same step with every collective switched off (each rank on its own from here
+        # on -- after the timed region, nothing reads these weights again).  The difference is the communication the
+        # three-bucket overlap did NOT hide.
+        eng.dp = False
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.train_step(x, y, m, p, lam_grad=LOSS["lam_grad"])
+        sync()
+        dt0 = time.perf_counter() - t1
+        tt = torch.tensor([dt0], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt0 = float(tt)
+        eng.dp = True
+        dp_diag = {"ms_per_step_without_collectives": round(1e3 * dt0 / a.steps, 4),
+                   "exposed_communication_ms": round(1e3 * (dt - dt0) / a.steps, 4),
+                   "buckets_bytes": [4 * eng.n_dec, 4 * (eng.n_bot - eng.n_dec), 4 * (eng.flat_g.numel() - eng.n_bot)]}
     line = {
         "metric": "train samples/s, cond. U-Net 128x64 grid (full training step)", "value": round(value, 2),
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -279,6 +346,8 @@ def main():
         "final_loss": loss_last,
         # the metric's "infer" half: UNet.forward (solpex/models.py:205-208) under no_grad, same batch / dtype, all ranks
     }
+    if dp_diag is not None:
+        line["dp"] = dp_diag
     if infer is not None:
         line["infer"] = {"value": round(infer, 2), "unit": "samples/s", "batch_per_gpu": a.batch,
                          "what": "UNet.forward(x, params), eval mode, no_grad, inputs resident in HBM"}
@@ -299,11 +368,21 @@ def main():
             step_flops = 7.272e9 * a.batch
             line["step_model_tflops"] = round(step_flops * a.steps / dt / 1e12, 2)
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is a single-GPU-run item (rank 0, N = 1 only)
-            torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "16")))
+            # threads: the job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count() reports the whole
+            # machine); "cores" = the threads the oracle actually ran on, host_cpu_count = what the host reports
+            threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), os.cpu_count() or 1))
+            torch.set_num_threads(threads)
             v, secs = cpu_baseline(a.cpu_batch, a.cpu_steps)
             line["cpu_baseline"] = {"value": round(v, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
-                                    "kind": "port", "sample": f"{a.cpu_steps} full training steps at batch {a.cpu_batch} "
+                                    "host_cpu_count": os.cpu_count(), "kind": "port",
+                                    "sample": f"{a.cpu_steps} full training steps at batch {a.cpu_batch} "
                                     f"(fp32, same model/grid/loss/optimizer), {secs:.1f} s"}
+            # BASELINE configs[0] (the reference's own CPU-runnable case) beside it: forward + masked MSE, batch 8, fp32
+            g_v, g_loss = config1_gpu(dev)
+            c_v, c_loss = config1_cpu()
+            line["config1"] = {"workload": "BASELINE configs[0]: forward + masked MSE, batch 8, 128x64, fp32",
+                               "gpu_samples_per_s": round(g_v, 1), "cpu_samples_per_s": round(c_v, 1), "cpu_threads": threads,
+                               "loss_gpu": g_loss, "loss_cpu": c_loss}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

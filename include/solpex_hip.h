@@ -102,6 +102,21 @@ int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, cons
                             const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, float* ch_sum,
                             int ch_sum_n, void* stream);
 
+/* sx_conv_forward_gn_bwd_sums: a 3x3 / 1x1 convolution whose OUTPUT y is the gradient w.r.t. the output of
+ * GroupNorm + SiLU (gn_mode 0: y = dA1 = conv2's data gradient, models.py:66-69) or w.r.t. a DoubleConv block output
+ * (gn_mode 2: FiLM, dropout and the residual in front of the second GroupNorm, models.py:80,152-156), with phase 1 of
+ * that GroupNorm's backward fused into the epilogue:
+ *   sums[b][c] += { sum dz*n_hat, sum dz, sum y*R, sum y }  (as sx_gn_silu_backward; last two for gn_mode 2 only)
+ * gn_y = the raw convolution output that GroupNorm normalised (same pixel grid as y), gn_s = the block's shortcut
+ * branch (gn_mode 2), stats / gamma / beta / film_g / drop as in sx_gn_silu_backward.  Follow with
+ * sx_gn_silu_backward(mode | SX_GN_BWD_SUMS_READY).  Shapes the fused kernel does not cover run the convolution and
+ * the reduction as two launches, same results. */
+int sx_conv_forward_gn_bwd_sums(int dtype, int mode, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
+                                const void* packed, void* y, int y_ld, int gn_mode, const void* gn_y, int gn_y_ld,
+                                const void* gn_s, int gn_s_ld, const float* stats, int groups, float eps,
+                                const float* gamma, const float* beta, const float* film_g, const float* drop,
+                                float* sums, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * sx_conv_wgrad: weight gradient as a split-K MFMA GEMM over pixels (weight half of
  * aten::convolution_backward for models.py:66,69,73-77,127,132).
@@ -154,6 +169,9 @@ int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, int groups,
                               const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
                               const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
                               void* r_out, int r_ld, void* pool, int pool_ld, void* stream);
+/* mode | SX_GN_BWD_SUMS_READY: `sums` entries were already accumulated by the producer of d_out
+ * (sx_conv_forward_gn_bwd_sums, sx_maxpool2_backward_gn_sums): only the element-wise phase runs. */
+#define SX_GN_BWD_SUMS_READY 4
 int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
                         int y_ld, const float* stats, const float* gamma, const float* beta,
                         const void* d_out, int do_ld, const void* r, int r_ld, const float* film_g,
@@ -249,6 +267,15 @@ int sx_norm_apply(int dtype, int inverse, int B, int C, int H, int W, const void
 int sx_masked_err_sums(int dtype, int denorm, int B, int C, int H, int W, const void* pred, int64_t sb, int64_t sc,
                        int64_t sh, int64_t sw, const float* target, const float* mask, const int* kinds, const float* mu,
                        const float* sigma, const float* eps, const float* scale, float* out, void* stream);
+
+/* sx_loss_ev_l1: the optional physical-space term of train_unet's loss (train.py:200-205, lam_ev > 0):
+ *   loss_ev = sum |inverse(pred)*m - inverse(target)*m| * m / max(sum m, 1e-8)   (numerator over channels, denominator pixels)
+ * den = DEVICE pointer to sum(mask) of the whole (global) batch (den[0] of sx_loss_prepare).  out[0] (nullable) += lam * loss_ev;
+ * d_pred (nullable; NHWC `dtype`) += lam * grad_scale * d loss_ev / d pred -- call after sx_loss_forward_backward. */
+int sx_loss_ev_l1(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld, const float* target,
+                  const float* mask, const int* kinds, const float* mu, const float* sigma, const float* eps,
+                  const float* scale, const float* den, float lam, float* out, void* d_pred, int dpred_ld,
+                  float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (train.py:82,226-233): grad-norm, clip_grad_norm_, AdamW over one flat fp32 arena.

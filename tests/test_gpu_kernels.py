@@ -343,6 +343,63 @@ def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode,gn_mode,B,H,W,Cin,Cout", [
+    # 3x3 producers of dA1 (GroupNorm-1 sums) at every tile family of the weights-stationary kernel, and shapes it does not
+    # cover (two launches); 1x1 producers of a block's d_out (four sums, FiLM / dropout factors, shortcut branch)
+    (0, 0, 3, 32, 16, 32, 32), (0, 0, 2, 64, 32, 64, 64), (0, 0, 2, 32, 16, 128, 128), (0, 0, 5, 16, 8, 256, 256),
+    (0, 0, 2, 13, 7, 16, 24), (0, 0, 3, 20, 16, 64, 64), (0, 0, 2, 8, 8, 128, 128),
+    (1, 2, 3, 32, 16, 8, 32), (1, 2, 2, 24, 32, 16, 64), (1, 2, 2, 16, 8, 32, 128), (1, 2, 2, 9, 5, 8, 16)])
+def test_conv_forward_with_fused_groupnorm_backward_sums(L, dtype, mode, gn_mode, B, H, W, Cin, Cout):
+    """sx_conv_forward_gn_bwd_sums == sx_conv_forward followed by phase 1 of sx_gn_silu_backward on its output."""
+    g = torch.Generator().manual_seed(B * 100 + Cin + Cout + mode)
+    k = 3 if mode == 0 else 1
+    G = min(8, Cout)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    yn = q(torch.randn(B, Cout, H, W, generator=g) * 1.5 + 0.3, dtype)          # the tensor GroupNorm normalised
+    sb = q(torch.randn(B, Cout, H, W, generator=g), dtype)                      # shortcut branch (gn_mode 2)
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+    gf = (1 + 0.3 * torch.randn(B, Cout, generator=g)).cuda()
+    drop = ((torch.rand(B, Cout, generator=g) > 0.3).float() / 0.7).cuda()
+    stats = torch.stack([yn.view(B, G, -1).sum(-1), (yn * yn).view(B, G, -1).sum(-1)], -1).contiguous().cuda()
+    xd, ynd, sbd = nhwc(x, dtype), nhwc(yn, dtype), nhwc(sb, dtype)
+    wp = pack(L, dtype, mode, 0, w, Cout, Cin, Cout, Cin)
+    gd, bd = gamma.cuda(), beta.cuda()
+    lib = L.lib()
+
+    def run(fused):
+        y = torch.empty(B, H, W, Cout, dtype=tdt(dtype), device="cuda")
+        sums = torch.zeros(B, Cout, 4, device="cuda")
+        dy = torch.empty_like(y)
+        dr = torch.empty_like(y)
+        fg, dp = (gf, drop) if gn_mode == 2 else (None, None)
+        if fused:
+            L.check(lib.sx_conv_forward_gn_bwd_sums(dtype, mode, B, H, W, Cin, Cout, L.ptr(xd), Cin, L.ptr(wp), L.ptr(y), Cout, gn_mode,
+                                                    L.ptr(ynd), Cout, L.ptr(sbd) if gn_mode == 2 else None, Cout, L.ptr(stats), G, 1e-5,
+                                                    L.ptr(gd), L.ptr(bd), L.ptr(fg), L.ptr(dp), L.ptr(sums), L.stream_ptr()))
+            flag = L.SX_GN_BWD_SUMS_READY
+        else:
+            L.check(lib.sx_conv_forward(dtype, mode, B, H, W, Cin, Cout, L.ptr(xd), Cin, H, W, L.ptr(wp), None, L.ptr(y), Cout, H, W,
+                                        0, None, 0, L.stream_ptr()))
+            flag = 0
+        L.check(lib.sx_gn_silu_backward(dtype, gn_mode | flag, B, H * W, Cout, G, 1e-5, L.ptr(ynd), Cout, L.ptr(stats), L.ptr(gd),
+                                        L.ptr(bd), L.ptr(y), Cout, L.ptr(sbd) if gn_mode == 2 else None, Cout, L.ptr(fg), L.ptr(dp),
+                                        L.ptr(sums), L.ptr(dy), Cout, L.ptr(dr) if gn_mode == 2 else None, Cout, None, None, 0,
+                                        L.stream_ptr()))
+        torch.cuda.synchronize()
+        return y.float().cpu(), sums.cpu(), dy.float().cpu()
+    y0, s0, d0 = run(False)
+    y1, s1, d1 = run(True)
+    assert torch.equal(y0, y1)
+    ns = 4 if gn_mode == 2 else 2
+    assert float(s1[..., ns:].abs().max()) == 0.0 if ns < 4 else True
+    for kk in range(ns):
+        scale = float(s0[..., kk].abs().max())
+        assert float((s1[..., kk] - s0[..., kk]).abs().max()) < 2e-4 * max(scale, 1e-6), (kk, scale)
+    assert rel_err(d1, d0) < (1e-5 if dtype == 0 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cc,film", [(2, 16, 8, 16, True), (3, 6, 10, 24, False), (2, 32, 16, 64, True), (1, 8, 8, 512, True)])
 def test_block_out_pool_forward_is_block_out_then_maxpool(L, dtype, B, H, W, Cc, film):
     """The fused encoder-block epilogue against the two calls it replaces: out, R and the pooled tensor bit-identical

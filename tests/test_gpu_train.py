@@ -183,3 +183,71 @@ def test_engine_dp_code_path_single_process_equals_plain_step():
         grads.append({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
     for k in grads[0]:
         assert rel_err(grads[1][k], grads[0][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_loss_ev_l1_value_and_gradient_match_reference(golden, dtype):
+    """sx_loss_ev_l1 (the lam_ev > 0 term, solpex/train.py:200-205) against the live reference's autograd on Log / SymLog /
+    Linear channels, a mask with holes and an all-empty sample."""
+    from unet_amd import _lib as L
+    from unet_amd.data import norm_table
+    g = golden("train_history.npz")
+    pred, tgt, mask = t(g["ev_pred"]), t(g["ev_target"]), t(g["ev_mask"])
+    B, Cc, H, W = pred.shape
+    tdt = torch.bfloat16 if dtype == 1 else torch.float32
+    pq = pred.to(tdt).float()                       # what the device sees
+    pd = pq.permute(0, 2, 3, 1).contiguous().to(tdt).cuda()
+    dp = torch.full((B, H, W, Cc), 0.25, dtype=tdt, device="cuda")      # the term ADDS to an existing gradient
+    out = torch.zeros(4, device="cuda")
+    den = mask.sum().reshape(1).cuda()
+    tab = norm_table(_norm(), Cc)
+    lam, gs = 0.3, 0.5
+    tgt_d, mask_d = tgt.cuda().contiguous(), mask.cuda().contiguous()       # keep them alive across the call
+    L.check(L.lib().sx_loss_ev_l1(dtype, B, Cc, H, W, L.ptr(pd), Cc, L.ptr(tgt_d), L.ptr(mask_d),
+                                  *tab.c_args(), L.ptr(den), lam, L.ptr(out), L.ptr(dp), Cc, gs, L.stream_ptr()))
+    torch.cuda.synchronize()
+    if dtype == 0:
+        assert abs(float(out[0]) - lam * float(g["ev_loss"])) < 1e-5 * lam * float(g["ev_loss"])
+        got = (dp.float().cpu().permute(0, 3, 1, 2) - 0.25) / (lam * gs)
+        assert rel_err(got, g["ev_grad"]) < 1e-5
+    else:
+        # bf16 predictions: compare with the oracle on the rounded inputs
+        from oracle import norm_ref
+        specs = [norm_ref.NormSpec(kind=(0, 2, 1)[i % 3], mu=float(n.mu), sigma=float(n.sigma),
+                                   eps=float(getattr(n, "eps", 0.0)), scale=float(getattr(n, "scale", 1.0)))
+                 for i, n in enumerate(_norm().norms.values())]
+        pr = pq.clone().requires_grad_(True)
+        ref = ((norm_ref.norm_inverse(specs, pr, mask) - norm_ref.norm_inverse(specs, tgt, mask)).abs() * mask).sum() / mask.sum().clamp_min(1e-8)
+        ref.backward()
+        assert abs(float(out[0]) - lam * float(ref)) < 1e-4 * lam * float(ref)
+        got = (dp.float().cpu().permute(0, 3, 1, 2) - 0.25) / (lam * gs)
+        assert rel_err(got, pr.grad) < 2e-2          # the sum 0.25 + g is stored in bf16
+
+
+def test_train_unet_with_lam_ev_matches_reference_history(golden, tmp_path):
+    """train_unet(lam_ev=0.05): the reference's two-epoch history with the physical-space L1 term on (fp32)."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import train_unet
+    from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8
+    g = golden("train_history.npz")
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=4)
+    tr = make_batch(6, 16, 8, seed=100, jitter_masks=True)
+    va = make_batch(4, 16, 8, seed=101, jitter_masks=True)
+    tl = torch.utils.data.DataLoader(_ListDS(tr), batch_size=2, shuffle=False)
+    vl = torch.utils.data.DataLoader(_ListDS(va), batch_size=2, shuffle=False)
+
+    def mk(in_ch, out_ch):
+        m = UNet(in_ch=in_ch, out_ch=out_ch, base=8, P=5, film_hidden=16, depth=2)
+        m.load_state_dict(sd)
+        return m
+    model, hist = train_unet(tl, vl, _norm(), 1, "cuda", out_ch=8, lam_grad=0.1, lam_w=0.5, lam_ev=0.05, epochs=2, base=8,
+                             model_cls=mk, P=5, film_hidden=16, depth=2, save_path=str(tmp_path / "ev.pt"), multiscale=1,
+                             lr_init=2e-3, amp=False, lam_grad_warmup_start=0, lam_grad_warmup_end=1,
+                             channel_weights=CHANNEL_WEIGHTS_8)
+    for k in ("tr_mse", "tr_maeN", "va_mse", "va_maeN", "va_mae_eV", "va_rmse_eV", "lr"):
+        np.testing.assert_allclose(np.asarray(hist[k]), g["ev_hist_" + k], rtol=5e-4, err_msg=k)
+    fin = model.state_dict()
+    for k in ("out.weight", "encoders.0.net.0.weight"):
+        assert rel_err(fin[k].cpu(), g["ev_final::" + k]) < 2e-3, k

@@ -333,6 +333,24 @@ def train_case():
     arrs["ckpt_keys"] = np.asarray(sorted(ck.keys()))
     arrs["ckpt_epoch"] = ck["epoch"]
     arrs["norm_kinds"] = np.asarray([i % 3 for i in range(8)])
+    # the same run with the physical-space L1 term switched on (train.py:200-205, lam_ev > 0)
+    model_ev, hist_ev = ref.train_unet(tl, vl, norm, 1, "cpu", out_ch=8, lam_grad=0.1, lam_w=0.5, lam_ev=0.05, epochs=2, base=8,
+                                       model_cls=mk, P=5, film_hidden=16, depth=2, save_path=path, multiscale=1,
+                                       lr_init=2e-3, amp=False, lam_grad_warmup_start=0, lam_grad_warmup_end=1,
+                                       channel_weights=CHANNEL_WEIGHTS_8, log_every=1)
+    for k, v in hist_ev.items():
+        arrs[f"ev_hist_{k}"] = np.asarray(v, dtype=np.float64)
+    fin_ev = model_ev.state_dict()
+    arrs["ev_final::out.weight"] = fin_ev["out.weight"]
+    arrs["ev_final::encoders.0.net.0.weight"] = fin_ev["encoders.0.net.0.weight"]
+    # the term alone, value and gradient, on a given prediction (the expression of train.py:202-204 on the live normalizer)
+    g = torch.Generator().manual_seed(12)
+    pe = (0.8 * torch.randn(3, 8, 16, 8, generator=g)).requires_grad_(True)
+    ye = 0.8 * torch.randn(3, 8, 16, 8, generator=g)
+    me = make_batch(3, 16, 8, seed=102, jitter_masks=True, empty_last=True)["mask"]
+    loss_ev = ((norm.inverse(pe.float(), me.float()) - norm.inverse(ye.float(), me.float())).abs() * me.float()).sum() / me.sum().clamp_min(1e-8)
+    loss_ev.backward()
+    arrs.update(ev_pred=pe.detach(), ev_target=ye, ev_mask=me, ev_loss=loss_ev.detach(), ev_grad=pe.grad)
     save("train_history.npz", **arrs)
 
 

@@ -21,6 +21,7 @@ SX_BWD_WEIGHT_GRADS, SX_BWD_ACCUMULATE, SX_BWD_ZERO_DPARAMS, SX_BWD_DEFER_FILM =
 SX_BWD_ONLY_BOTTLENECK, SX_BWD_AFTER_BOTTLENECK, SX_BWD_NO_DPARAMS = 16, 32, 64
 SX_NORM_LOG, SX_NORM_LINEAR, SX_NORM_SYMLOG = 0, 1, 2
 SX_WGRAD_STATIC_BYTES = 32 << 20
+SX_GN_BWD_SUMS_READY = 4
 PX_KINDS = {"huber": 0, "l1": 1, "mse": 2}
 
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     "sx_packed_weight_elems": (_l, [_i, _i, _i, _i]),
     "sx_pack_conv_weight": (_i, [_i, _i, _i, _p, _i, _i, _p, _p]),
     "sx_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "sx_conv_forward_gn_bwd_sums": (_i, [_i] * 7 + [_p, _i, _p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),
     "sx_conv_wgrad_workspace_bytes": (_l, [_i] * 6),
     "sx_conv_wgrad": (_i, [_i] * 9 + [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p]),
     "sx_conv_wgrad_static": (_i, [_i] * 9 + [_p, _i, _p, _i, _i, _i, _p, _i, _p]),
@@ -71,6 +73,7 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _i, _f, _p]),
     "sx_norm_apply": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sx_masked_err_sums": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "sx_loss_ev_l1": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _f, _p]),
     "sx_grad_sumsq": (_i, [_p, _l, _p, _p]),
     "sx_conv3_shortcut_forward": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
     "sx_conv3_shortcut_dgrad": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p]),

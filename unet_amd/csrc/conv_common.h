@@ -35,6 +35,18 @@ struct ConvArgs {
   unsigned long long* stamps;
   int kc0;            // first 32-wide K chunk of the packed weights this launch covers (K slices, see KRow)    // diagnostic build (-DSX_WS_DBG=1) only: per-block s_memtime stamps
   float* ch_sum; int ch_sum_n;   // optional: ch_sum[c] += sum over all output pixels of y[..., c], c < ch_sum_n (atomics)
+  // WS_BS: y is the gradient w.r.t. the output of GroupNorm + SiLU (bs_mode 1) or of a whole DoubleConv block output
+  // (bs_mode 2: FiLM, dropout, residual in front); the epilogue accumulates the per-(sample, channel) sums GroupNorm's
+  // backward needs (norm_act.hip: act_bwd_reduce_kernel) while the values are in registers:
+  //   sums[b][c] += { sum dz * n_hat, sum dz, sum y * R, sum y },  dz = y * gf * drop * silu'(z)      (last two: mode 2)
+  int bs_mode;
+  const void* bs_y; int bs_y_ld;        // raw convolution output the GroupNorm normalised, same pixel grid as y
+  const void* bs_s; int bs_s_ld;        // mode 2: the block's shortcut branch
+  const float* bs_stats;                // [B][G][2] sum / sum of squares (cpg = channels per group, bs_inv_n = 1 / (cpg * H * W))
+  const float* bs_gamma; const float* bs_beta;
+  const float* bs_gf; const float* bs_drop;   // [B][C] FiLM scale, dropout factor (nullable)
+  float* bs_sums;                       // [B][C][4], zeroed by the caller
+  float bs_eps, bs_inv_n;
 };
 
 template <typename T> struct Mma;
@@ -57,7 +69,7 @@ template <> struct Mma<float> {
 // weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
 // var: 0 plain; WS_DUAL: y2 = conv1x1(x, w2) beside the 3x3 (same input tile); WS_CENTER: the input has 2K channels and
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
-enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2 };
+enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
 
 // Weight packing for a whole table of layers in one launch (conv_igemm.hip).

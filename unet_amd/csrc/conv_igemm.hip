@@ -16,6 +16,7 @@
 // into LDS (rows padded to 96 B: conflict-free for the ds_read_b128 fragment reads), then every
 // wave runs ntaps x MI x NI MFMAs on fragments read straight from those two images.
 #include "conv_common.h"
+#include "norm_act.h"
 #include <vector>
 #include <stdlib.h>
 
@@ -458,6 +459,40 @@ extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin
     if (rc <= 0) return rc;
   }
   return dtype == SX_BF16 ? conv_dispatch<bf16>(a, st) : conv_dispatch<float>(a, st);
+}
+
+// y = conv(x) where y is a gradient entering GroupNorm + SiLU backward: phase 1 of that backward in the epilogue
+extern "C" int sx_conv_forward_gn_bwd_sums(int dtype, int mode, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
+                                           const void* packed, void* y, int y_ld, int gn_mode, const void* gn_y, int gn_y_ld,
+                                           const void* gn_s, int gn_s_ld, const float* stats, int groups, float eps,
+                                           const float* gamma, const float* beta, const float* film_g, const float* drop,
+                                           float* sums, void* stream) {
+  SX_REQUIRE(x && packed && y && gn_y && stats && gamma && beta && sums, "sx_conv_forward_gn_bwd_sums: null pointer");
+  SX_REQUIRE(mode == SX_CONV3 || mode == SX_CONV1, "sx_conv_forward_gn_bwd_sums: 3x3 / 1x1 only");
+  SX_REQUIRE(gn_mode == 0 || (gn_mode == 2 && gn_s), "sx_conv_forward_gn_bwd_sums: gn_mode 0, or 2 with the shortcut branch");
+  SX_REQUIRE(groups > 0 && Cout % groups == 0, "sx_conv_forward_gn_bwd_sums: groups %d do not divide %d channels", groups, Cout);
+  if (dtype == SX_BF16 && Cin % 8 == 0 && x_ld % 8 == 0 && Cout % 4 == 0 && y_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
+      ((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)gn_y % 8) == 0 &&
+      (!gn_s || ((uintptr_t)gn_s % 8) == 0)) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = packed; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.x_ld = x_ld; a.Hy = H; a.Wy = W; a.y_ld = y_ld;
+    a.K = Cin; a.KPad = round_up(Cin, 32);
+    a.R = Cout; a.RPad = round_up(Cout, 16); a.RTot = a.RPad;
+    if (mode == SX_CONV3) { a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1; }
+    else { a.ntaps = 1; a.tapw = 1; a.in_scale = 1; a.pad = 0; }
+    a.cpg = Cout / groups;
+    a.bs_mode = gn_mode == 2 ? 2 : 1;
+    a.bs_y = gn_y; a.bs_y_ld = gn_y_ld; a.bs_s = gn_s; a.bs_s_ld = gn_s_ld;
+    a.bs_stats = stats; a.bs_gamma = gamma; a.bs_beta = beta; a.bs_gf = film_g; a.bs_drop = drop; a.bs_sums = sums;
+    a.bs_eps = eps; a.bs_inv_n = 1.0f / ((float)a.cpg * (float)H * (float)W);
+    const int rc = conv_ws_try(a, mode, (hipStream_t)stream, WS_BS);
+    if (rc <= 0) return rc;
+  }
+  SX_TRY(sx_conv_forward(dtype, mode, B, H, W, Cin, Cout, x, x_ld, H, W, packed, nullptr, y, y_ld, H, W, 0, nullptr, 0, stream));
+  return gn_bwd_reduce_only(dtype, gn_mode, B, H * W, Cout, groups, eps, gn_y, gn_y_ld, stats, gamma, beta, y, y_ld, gn_s, gn_s_ld,
+                            film_g, drop, sums, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ DoubleConv fusions (models.py:60-96)

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   constexpr int DIST = NBUF - 1;                // stages in flight
   constexpr int KTOT = VAR == WS_CENTER ? 2 * KCH : KCH;   // K chunks (= pipeline stages) per tile
   constexpr int CT = TAPS / 2;                  // centre tap
-  static_assert(VAR == WS_PLAIN || TAPS == 9, "fused variants are 3x3 only");
+  static_assert(VAR == WS_PLAIN || VAR == WS_BS || TAPS == 9, "fused variants are 3x3 only");
+  constexpr bool BS = VAR == WS_BS;
+  // (block-output sums -- four per channel, FiLM / dropout factors, for the 1x1 head's data gradient -- were built and
+  // measured: 45 us fused against 17 + 26 us for the two launches.  A 1x1 launch is all epilogue, and at one wave per SIMD
+  // nothing hides the sigmoid's latency; the stand-alone reduction runs the same arithmetic at 8 waves per SIMD.)
+  constexpr bool BS2 = false;
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __align__(16) char smem[];
   float* sm_stat = reinterpret_cast<float*>(smem + NBUF * BUF);   // [WN][BMC][2]
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       }
   }
   // 1x1 weights of the fused variants: A2[kc][j] = W2[cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
-  bf16x8 A2[VAR == WS_PLAIN ? 1 : KCH][MI];
-  if constexpr (VAR != WS_PLAIN) {
+  bf16x8 A2[(VAR == WS_PLAIN || BS) ? 1 : KCH][MI];
+  if constexpr (VAR == WS_DUAL || VAR == WS_CENTER) {
     const bf16* __restrict__ wg2 = reinterpret_cast<const bf16*>(a.w2);
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
@@ -180,6 +185,81 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < MI; ++j) { s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j]; }
 
+  // ---- WS_BS: fused GroupNorm-backward sums.  A lane's channels never change, so gamma / beta stay in registers; the
+  // statistics of its channels' group and the FiLM / dropout factors are reloaded when the sample changes.
+  constexpr bool bs2 = BS2;
+  f32x4 s3[BS2 ? MI : 1], s4[BS2 ? MI : 1];
+  f32x4 bs_ga[BS ? MI : 1], bs_be[BS ? MI : 1], bs_fac[BS2 ? MI : 1], bs_drp[BS2 ? MI : 1];
+  float bs_rs[BS ? MI : 1], bs_mr[BS ? MI : 1];
+  const bf16* __restrict__ bsY = reinterpret_cast<const bf16*>(a.bs_y);
+  const bf16* __restrict__ bsS = reinterpret_cast<const bf16*>(a.bs_s);
+  const int lane_bsy = ((wn * NI * RPF + nr) * a.Wy + nc) * a.bs_y_ld + cb + wm * MI * 16 + 4 * g;
+  const int lane_bss = ((wn * NI * RPF + nr) * a.Wy + nc) * a.bs_s_ld + cb + wm * MI * 16 + 4 * g;
+  auto bs_sample = [&](int b) {
+    if constexpr (BS) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int c = min(cb + (wm * MI + j) * 16 + 4 * g, a.R - 4);
+        const float* stp = a.bs_stats + ((int64_t)b * (a.R / a.cpg) + c / a.cpg) * 2;
+        const float mean = stp[0] * a.bs_inv_n;
+        const float var = fmaxf(stp[1] * a.bs_inv_n - mean * mean, 0.f);
+        const float r = rsqrtf(var + a.bs_eps);
+        bs_rs[j] = r;
+        bs_mr[j] = mean * r;
+        if constexpr (BS2) {
+          f32x4 f = {1.f, 1.f, 1.f, 1.f}, d = f;
+          if (a.bs_drop) d = *reinterpret_cast<const f32x4*>(a.bs_drop + (int64_t)b * a.R + c);
+          if (a.bs_gf) f = *reinterpret_cast<const f32x4*>(a.bs_gf + (int64_t)b * a.R + c);
+          bs_drp[j] = d;
+          bs_fac[j] = f * d;
+        }
+      }
+    }
+  };
+  if constexpr (BS) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int c = min(cb + (wm * MI + j) * 16 + 4 * g, a.R - 4);
+      bs_ga[j] = *reinterpret_cast<const f32x4*>(a.bs_gamma + c);
+      bs_be[j] = *reinterpret_cast<const f32x4*>(a.bs_beta + c);
+      if constexpr (BS2) { s3[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s4[j] = s3[j]; }
+    }
+    bs_sample(cp.b);
+  }
+  // per-(sample, channel) flush: DPP row sums -> LDS -> one atomic per channel and sum
+  auto flush_bs = [&](int b) {
+    if constexpr (BS) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int cl = (wm * MI + j) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t1 = s1[j][r], t2 = s2[j][r], t3 = 0.f, t4 = 0.f;
+          if constexpr (BS2) { t1 *= bs_fac[j][r]; t2 *= bs_fac[j][r]; t3 = row_sum16(s3[j][r]); t4 = row_sum16(s4[j][r]); }
+          t1 = row_sum16(t1); t2 = row_sum16(t2);
+          if (n == 0) *reinterpret_cast<f32x4*>(sm_stat + (wn * BMC + cl + r) * 4) = f32x4{t1, t2, t3, t4};
+        }
+        s1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s2[j] = s1[j];
+        if constexpr (BS2) { s3[j] = s1[j]; s4[j] = s1[j]; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int ns = bs2 ? 4 : 2;
+      for (int o = tid; o < BMC * ns; o += 256) {
+        const int cl = o / ns, k = o - cl * ns;
+        if (cb + cl < a.R) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < WN; ++w) t += sm_stat[(w * BMC + cl) * 4 + k];
+          atomicAdd(a.bs_sums + ((int64_t)b * a.R + cb + cl) * 4 + k, t);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // sm_stat may be rewritten by the next flush
+    }
+  };
+
   auto flush_stats = [&](int b) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
@@ -221,6 +301,11 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
   for (int t = t_begin; t < t_end; ++t) {
     f32x4 acc[MI][NI], acc2[VAR == WS_DUAL ? MI : 1][VAR == WS_DUAL ? NI : 1];
+    // register-heavy instantiations (288 weight VGPRs and two channel fragments per wave) prefetch the first fragment row
+    // only; the second is fetched at the top of the epilogue, under the arithmetic of the first
+    constexpr bool BS_HEAVY = BS && MI == 2 && KCH * TAPS * MI * 4 >= 288;
+    constexpr int PJ = BS ? (BS_HEAVY ? 1 : MI) : 1;
+    bf16x4 ypre[PJ][BS ? NI : 1], ylate[BS_HEAVY ? NI : 1];
 #pragma unroll
     for (int j = 0; j < MI; ++j)
 #pragma unroll
@@ -235,6 +320,25 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
       if (WS_DBG && s == 0) t_first = __builtin_amdgcn_s_memtime();
+      if constexpr (BS) {
+        // the GroupNorm input at this tile's output pixels, fetched under the last stage's MFMAs.  Issued BEFORE the stage's
+        // DMA: vmcnt retires in order, so waiting for these loads later must not wait for the newest prefetch stage too
+        if (kc == KTOT - 1) {
+          const bf16* yt = bsY + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.bs_y_ld;
+          const bool xv = cp.tx * TW + nc < a.W;
+          const int rl = a.H - cp.ty * TH - wn * NI * RPF - nr;
+#pragma unroll
+          for (int j = 0; j < PJ; ++j) {
+            const bool cv = cb + (wm * MI + j) * 16 + 4 * g < a.R;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+              bf16x4 v = {};
+              if (cv && xv && i * RPF < rl) v = *reinterpret_cast<const bf16x4*>(yt + (unsigned)(lane_bsy + i * RPF * a.Wy * a.bs_y_ld + j * 16));
+              ypre[j][i] = v;
+            }
+          }
+        }
+      }
       issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
       const char* buf = smem + (s % NBUF) * BUF + frag_off;
       if constexpr (VAR == WS_CENTER) {
@@ -300,7 +404,17 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
           }
         }
       }
-    } else
+    } else {
+    if constexpr (BS_HEAVY) {
+      const bf16* yt = bsY + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.bs_y_ld;
+      const bool cv = cb + (wm * MI + 1) * 16 + 4 * g < a.R;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        bf16x4 v = {};
+        if (cv && xvalid && i * RPF < rows_left) v = *reinterpret_cast<const bf16x4*>(yt + (unsigned)(lane_bsy + i * RPF * a.Wy * a.bs_y_ld + 16));
+        ylate[i] = v;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const bool cvalid = cb + (wm * MI + j) * 16 + 4 * g < a.R;
@@ -310,6 +424,28 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         if (cvalid && xvalid && i * RPF < rows_left) {
           bf16* dst = ytile + (unsigned)(lane_out + i * RPF * out_row + j * 16);
           if (a.accumulate) v += load4(dst);
+          if constexpr (BS) {
+            // sums from the value as STORED (bf16), exactly what the element-wise apply pass will read back
+            const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(dst) = o;
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (bs2) sv = load4(bsS + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.bs_s_ld + (unsigned)(lane_bss + i * RPF * a.Wy * a.bs_s_ld + j * 16));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gq = (float)o[r];
+              const float yq = (float)((BS_HEAVY && j >= PJ) ? ylate[i][r] : ypre[j < PJ ? j : 0][i][r]);
+              const float nh = yq * bs_rs[j] - bs_mr[j];
+              const float z = nh * bs_ga[j][r] + bs_be[j][r];
+              const float sg = sigmoidf_(z);
+              const float dz = gq * (sg * (1.0f + z * (1.0f - sg)));
+              s1[j][r] += dz * nh;
+              s2[j][r] += dz;
+              if constexpr (bs2) {
+                s3[j][r] += gq * ((z * sg + sv[r]) * bs_drp[j][r]);
+                s4[j][r] += gq;
+              }
+            }
+          } else
           store4(dst, v);
           if (do_stats) { s1[j] += v; s2[j] += v * v; }
           else if (do_chsum) s1[j] += v;
@@ -317,9 +453,16 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         }
       }
     }
+    }
     const int b_done = cp.b;
     cp.next(a.tiles_x, a.tiles_y);
     if (do_stats && (t + 1 == t_end || cp.b != b_done)) flush_stats(b_done);
+    if constexpr (BS) {
+      if (t + 1 == t_end || cp.b != b_done) {
+        flush_bs(b_done);
+        if (t + 1 < t_end) bs_sample(cp.b);
+      }
+    }
   }
   if (do_chsum && !do_stats) {       // one flush per block: the sums run over every sample
 #pragma unroll
@@ -357,7 +500,7 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int NPIX = (TH + TAPW - 1) * (TW + TAPW - 1);
   constexpr int NP = (NPIX * 4 + 255) / 256;
   constexpr int NBUF = 4;                                       // three stages in flight per block
-  const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * 2 * sizeof(float);
+  const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * (VAR == WS_BS ? 4 : 2) * sizeof(float);
   auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL, VAR>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_ws)"));
@@ -400,7 +543,10 @@ static int ws_pick_tile(const ConvArgs& a, hipStream_t st) {
     if constexpr (KCH <= 4 && !LIGHT) return launch_ws<KCH, TAPS, 2, 4, 2, 2, 4, VAR>(a, st);   // 64 ch x 128 px (8 rows)
     else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                                // 64 ch x 128 px
   } else {
-    if constexpr (KCH <= 4 && VAR == WS_PLAIN) return launch_ws<KCH, TAPS, 2, 8, 4, 1, 4, VAR>(a, st);   // 128 ch x 128 px
+    // (the fused-sums variant of the 288-weight-register tile spills and its one-tile blocks expose all of the extra
+    // arithmetic: measured 37.6 us against 19.9 + 10 us for convolution + separate reduction -> two launches there)
+    if constexpr (VAR == WS_BS && KCH * TAPS * 2 * 4 >= 288) return 1;
+    else if constexpr (KCH <= 4 && (VAR == WS_PLAIN || VAR == WS_BS)) return launch_ws<KCH, TAPS, 2, 8, 4, 1, 4, VAR>(a, st);   // 128 ch x 128 px
     else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                      // 64 ch x 128 px, grid.y = RTot/64
   }
 }
@@ -430,6 +576,14 @@ int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
   if (var == WS_DUAL) {
     if (mode != SX_CONV3 || a.accumulate || !a.w2 || !a.y2 || a.y2_ld % 4) return 1;
     return ws_pick_k<9, WS_DUAL>(a, st);
+  }
+  if (var == WS_BS) {
+    // fused GroupNorm-backward sums: a lane's four channels must share a group; no other epilogue extras
+    if (a.accumulate || a.gn_stats || a.ch_sum || a.KPad > 256 || a.cpg <= 0 || a.cpg % 4 || a.R % a.cpg) return 1;
+    if (a.bs_mode != 1 || mode != SX_CONV3) return 1;          // instantiated: 3x3 convolutions with GroupNorm + SiLU sums
+    if (!a.bs_y || !a.bs_stats || !a.bs_gamma || !a.bs_beta || !a.bs_sums || a.bs_y_ld % 4 || (a.bs_mode == 2 && (!a.bs_s || a.bs_s_ld % 4))) return 1;
+    if (((uintptr_t)a.bs_gamma | (uintptr_t)a.bs_beta | (uintptr_t)a.bs_gf | (uintptr_t)a.bs_drop | (uintptr_t)a.bs_sums) % 16) return 1;
+    return ws_pick_k<9, WS_BS>(a, st);
   }
   if (var == WS_CENTER) {
     if (mode != SX_CONV3 || !a.w2 || a.K % 32 || a.x_ld < 2 * a.K) return 1;

@@ -99,6 +99,55 @@ __global__ __launch_bounds__(256) void err_sums_kernel(NormTable t, int denorm, 
   if (threadIdx.x == 0) { atomicAdd(out + 0, v[0]); atomicAdd(out + 1, v[1]); atomicAdd(out + 2, v[2]); }
 }
 
+// Physical-space masked L1 term of the training loss (train.py:200-205) and its gradient:
+//   loss_ev = sum_{b,c,px} |inv(p)*m - inv(y)*m| * m / max(sum_{b,px} m, 1e-8)          (inv = the normalizer's inverse)
+//   out[0] += lam * loss_ev ;  d_pred[b,px,c] += lam * grad_scale * sign(.) * m * d inv(p)/dp / den
+// One thread per pixel walks the channels: 16-byte NHWC accesses of pred / d_pred, planar target reads coalesced per channel.
+// d inv/dp: log  exp(z) * (sigma + 1e-8) * m, z = p*(sigma+1e-8)+mu ; symlog  scale * exp(|u|) * sigma * m, u = p*sigma+mu ;
+// linear  sigma ; zero where the inverse is not finite (the reference's torch.where passes no gradient there).
+template <typename T>
+__global__ __launch_bounds__(256) void ev_l1_kernel(NormTable t, const T* __restrict__ pred, int pred_ld, const float* __restrict__ target,
+                                                    const float* __restrict__ mask, const float* __restrict__ den, float lam,
+                                                    float grad_mul, float* __restrict__ out, T* __restrict__ d_pred, int dpred_ld,
+                                                    int B, int C, int HW) {
+  const float inv_den = 1.0f / fmaxf(den[0], 1e-8f);
+  float v[1] = {0.f};
+  const int64_t npx = (int64_t)B * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npx; i += (int64_t)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    if (m == 0.f) continue;
+    const int b = (int)(i / HW);
+    const int64_t px = i - (int64_t)b * HW;
+    for (int c = 0; c < C; ++c) {
+      const float p = to_f32(pred[i * pred_ld + c]);
+      const float y = target[((int64_t)b * C + c) * HW + px];
+      const float pe = norm_inverse_one(t, c, p, m, true), ye = norm_inverse_one(t, c, y, m, true);
+      const float d = pe - ye;
+      v[0] += fabsf(d) * m;
+      if (d_pred) {
+        float dv;
+        const int kind = t.kind[c];
+        if (kind == SX_NORM_LINEAR) dv = t.sigma[c];
+        else if (kind == SX_NORM_LOG) {
+          const float e = expf(p * (t.sigma[c] + 1e-8f) + t.mu[c]);
+          dv = finite_or_zero(e - t.eps[c]) == e - t.eps[c] ? e * (t.sigma[c] + 1e-8f) * m : 0.f;
+        } else {
+          const float u = p * t.sigma[c] + t.mu[c];
+          const float yy = t.scale[c] * expm1f(fabsf(u));
+          dv = (finite_or_zero(yy) == yy && u != 0.f) ? t.scale[c] * expf(fabsf(u)) * t.sigma[c] * m : (u == 0.f ? t.scale[c] * t.sigma[c] * m : 0.f);
+        }
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float g = lam * grad_mul * inv_den * sg * m * dv;
+        T* dst = d_pred + i * dpred_ld + c;
+        *dst = from_f32<T>(to_f32(*dst) + g);
+      }
+    }
+  }
+  __shared__ float red[4];
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0 && out) atomicAdd(out, lam * v[0] * inv_den);
+}
+
 static int fill_table(NormTable& t, int C, const int* kinds, const float* mu, const float* sigma, const float* eps, const float* scale, const char* who) {
   if (C < 1 || C > SX_MAX_NORM_CH) { set_error("%s: %d channels (max %d)", who, C, SX_MAX_NORM_CH); return SX_ERR_UNSUPPORTED; }
   memset(&t, 0, sizeof(t));
@@ -145,5 +194,23 @@ extern "C" int sx_masked_err_sums(int dtype, int denorm, int B, int C, int H, in
   if (dtype == SX_BF16) hipLaunchKernelGGL(err_sums_kernel<bf16>, dim3(gsz2(n)), dim3(256), 0, st, t, denorm, (const bf16*)pred, sb, sc, sh, sw, target, mask, out, B, C, H, W);
   else hipLaunchKernelGGL(err_sums_kernel<float>, dim3(gsz2(n)), dim3(256), 0, st, t, denorm, (const float*)pred, sb, sc, sh, sw, target, mask, out, B, C, H, W);
   SX_LAUNCH_CHECK("masked_err_sums");
+  return SX_OK;
+}
+
+// lam_ev term of train_unet's loss (train.py:200-205).  den: DEVICE pointer to sum(mask) over the (global) batch; out[0] (nullable)
+// += lam * loss_ev; d_pred (nullable, NHWC `dtype`) += lam * grad_scale * d loss_ev / d pred (call after sx_loss_forward_backward).
+extern "C" int sx_loss_ev_l1(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld, const float* target,
+                             const float* mask, const int* kinds, const float* mu, const float* sigma, const float* eps,
+                             const float* scale, const float* den, float lam, float* out, void* d_pred, int dpred_ld,
+                             float grad_scale, void* stream) {
+  SX_REQUIRE(pred && target && mask && den && kinds && mu && sigma && eps && scale, "sx_loss_ev_l1: null pointer");
+  SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_loss_ev_l1: bad dtype %d", dtype);
+  NormTable t;
+  SX_TRY(fill_table(t, C, kinds, mu, sigma, eps, scale, "sx_loss_ev_l1"));
+  const int64_t npx = (int64_t)B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(ev_l1_kernel<bf16>, dim3(gsz2(npx)), dim3(256), 0, st, t, (const bf16*)pred, pred_ld, target, mask, den, lam, grad_scale, out, (bf16*)d_pred, dpred_ld, B, C, H * W);
+  else hipLaunchKernelGGL(ev_l1_kernel<float>, dim3(gsz2(npx)), dim3(256), 0, st, t, (const float*)pred, pred_ld, target, mask, den, lam, grad_scale, out, (float*)d_pred, dpred_ld, B, C, H * W);
+  SX_LAUNCH_CHECK("loss_ev_l1");
   return SX_OK;
 }

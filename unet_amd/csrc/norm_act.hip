@@ -477,6 +477,25 @@ extern "C" int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, 
   return SX_OK;
 }
 
+// phase 1 alone (the fallback of producers that could not fuse the sums into their epilogue); mode 0 or 2
+namespace sx {
+int gn_bwd_reduce_only(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y, int y_ld, const float* stats,
+                       const float* gamma, const float* beta, const void* d_out, int do_ld, const void* s, int s_ld,
+                       const float* film_g, const float* drop, float* sums, hipStream_t st) {
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dO = d_out; a.do_ld = do_ld;
+  a.R = s; a.r_ld = s_ld; a.gf = film_g; a.drop = drop; a.sums = sums;
+  a.B = B; a.HW = HW; a.C = C; a.G = groups; a.eps = eps;
+  SX_TRY(act_check(a, "gn_bwd_reduce"));
+  dim3 grid = mode ? act_grid(a, 1024) : act_grid(a);
+  if (mode == 2) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 2, grid, st, a); }
+  else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid, st, a); }
+  SX_LAUNCH_CHECK("gn_bwd_reduce");
+  return SX_OK;
+}
+}  // namespace sx
+
 // mode 0: gradient through A = silu(gn(Y));  mode 1: through the block output (FiLM, dropout, residual).
 // sums must be zeroed by the caller ([B][C][4] fp32).
 extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
@@ -485,7 +504,9 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
                                    const float* drop, float* sums, void* dy, int dy_ld, void* d_r, int dr_ld,
                                    float* dgamma, float* dbeta, int accumulate, void* stream) {
   SX_REQUIRE(y && stats && gamma && beta && d_out && sums && dy, "sx_gn_silu_backward: null pointer");
-  SX_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && r), "sx_gn_silu_backward: mode 1 needs the saved block sum R, mode 2 the shortcut branch S");
+  const bool sums_ready = (mode & SX_GN_BWD_SUMS_READY) != 0;      // the producer of d_out already accumulated `sums`
+  mode &= ~SX_GN_BWD_SUMS_READY;
+  SX_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && (r || sums_ready)), "sx_gn_silu_backward: mode 1 needs the saved block sum R, mode 2 the shortcut branch S");
   ActArgs a;
   memset(&a, 0, sizeof(a));
   a.Y = y; a.y_ld = y_ld; a.stats = stats; a.gamma = gamma; a.beta = beta; a.dO = d_out; a.do_ld = do_ld;
@@ -497,11 +518,13 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   hipStream_t st = (hipStream_t)stream;
   // the block-output pass (four sums, three tensors) pays more per block for its combine: half as many blocks
   dim3 grid_r = mode ? act_grid(a, 1024) : grid;
-  if (mode == 2) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 2, grid_r, st, a); }
-  else if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid_r, st, a); }
-  else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid_r, st, a); }
+  if (!sums_ready) {
+    if (mode == 2) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 2, grid_r, st, a); }
+    else if (mode) { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 1, grid_r, st, a); }
+    else { SX_DISPATCH_T(dtype, act_bwd_reduce_kernel, 0, grid_r, st, a); }
+    SX_LAUNCH_CHECK("gn_bwd_reduce");
+  }
   grid = act_grid(a);
-  SX_LAUNCH_CHECK("gn_bwd_reduce");
   if (mode) { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 1, grid, st, a); }
   else { SX_DISPATCH_T(dtype, act_bwd_apply_kernel, 0, grid, st, a); }
   SX_LAUNCH_CHECK("gn_bwd_apply");

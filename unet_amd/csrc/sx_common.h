@@ -105,7 +105,9 @@ __device__ __forceinline__ void store8(bf16* p, const f32x8& r) {
 }
 
 // ------------------------------------------------------------------ math
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE division here costs ~10 extra VALU instructions per element, and the
+// element-wise GroupNorm / SiLU passes sit close to their VALU floor (measured: see DESIGN.md, "element-wise passes")
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f)); }
 __device__ __forceinline__ float siluf_(float z) { return z * sigmoidf_(z); }
 __device__ __forceinline__ float dsiluf_(float z) {
   float s = sigmoidf_(z);

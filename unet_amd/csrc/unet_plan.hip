@@ -365,7 +365,7 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
 // d_out is read from b.dO.  Writes parameter gradients (if wg) and the input gradient into b.dX (if need_dx).
 static int block_backward(const Plan& p, int k, const float* const* params, float* const* grads, const void* wpack, void* ws,
                           bool film, const float* drop, bool need_dx, int flags, WgQueue& wq, hipStream_t st,
-                          float* ch_sum = nullptr, int ch_sum_n = 0) {
+                          float* ch_sum = nullptr, int ch_sum_n = 0, bool sums2_ready = false) {
   const BlockBuf& b = p.blk[k];
   const int dt = p.d.dtype, B = p.d.B, HW = b.H * b.W;
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
@@ -378,7 +378,7 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   const void* Rsrc = keep_r ? at(ws, b.S) : at(ws, b.O);
   const int r_ld = keep_r ? b.C : b.o_ld;
   // through FiLM / dropout / residual / SiLU / GN2
-  SX_TRY(sx_gn_silu_backward(dt, keep_r ? 2 : 1, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
+  SX_TRY(sx_gn_silu_backward(dt, (keep_r ? 2 : 1) | (sums2_ready ? SX_GN_BWD_SUMS_READY : 0), B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
                              at(ws, b.dO), b.C, Rsrc, r_ld, film ? (const float*)at(ws, b.gf) : nullptr, drop,
                              (float*)at(ws, b.sums2), at(ws, b.dY), b.C, at(ws, b.dR), 2 * b.C,
                              nullptr, nullptr, acc, st));
@@ -390,10 +390,12 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   if (wg) {
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
   }
-  SX_TRY(sx_conv_forward(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, b.H, b.W, at(wpack, b.w2d), nullptr,
-                         at(ws, b.dA1), b.C, b.H, b.W, 0, nullptr, 0, st));
-  // through SiLU / GN1 (its own buffer: the deferred weight-gradient launch still reads dY)
-  SX_TRY(sx_gn_silu_backward(dt, 0, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
+  // dA1 = W2^T (*) dY, with phase 1 of GroupNorm-1's backward (per-(sample, channel) sums) in the convolution's epilogue
+  SX_TRY(sx_conv_forward_gn_bwd_sums(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, at(wpack, b.w2d), at(ws, b.dA1), b.C,
+                                     0, at(ws, b.Y1), b.C, nullptr, 0, (const float*)at(ws, b.st1), b.G, GN_EPS, g1, be1,
+                                     nullptr, nullptr, (float*)at(ws, b.sums1), st));
+  // through SiLU / GN1, element-wise phase (its own buffer: the deferred weight-gradient launch still reads dY)
+  SX_TRY(sx_gn_silu_backward(dt, 0 | SX_GN_BWD_SUMS_READY, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
                              at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), 2 * b.C,
                              nullptr, 0, nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);

@@ -59,7 +59,7 @@ class TrainEngine:
     """Fused training / evaluation steps of a `unet_amd.models.UNet` on one GPU (or one DP rank)."""
 
     def __init__(self, model, *, dtype=torch.float32, lr=1e-3, weight_decay=1e-4, clip_grad=1.0, betas=(0.9, 0.999),
-                 eps=1e-8, channel_weights=None, w_map=None, loss_opts=None):
+                 eps=1e-8, channel_weights=None, w_map=None, loss_opts=None, lam_ev=0.0, norm=None):
         from .models import UNet
         if not isinstance(model, UNet):
             raise TypeError("TrainEngine drives unet_amd.models.UNet instances")
@@ -101,6 +101,14 @@ class TrainEngine:
                               multiscale=0, ms_weight=0.5, grad_ds=1)
         if loss_opts:
             self.loss_opts.update(loss_opts)
+        # optional physical-space L1 term of the training loss (reference: solpex/train.py:200-205)
+        self.lam_ev = float(lam_ev or 0.0)
+        self._ev_table = None
+        if self.lam_ev > 0:
+            if norm is None:
+                raise ValueError("TrainEngine: lam_ev > 0 needs the output normalizer (`norm`)")
+            from .data import norm_table
+            self._ev_table = norm_table(norm, self.cfg["out_ch"])
         self._sessions = {}
         self._ss = torch.zeros(2, dtype=torch.float32, device=self.device)   # ping-pong: the AdamW kernel clears the other slot
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -177,6 +185,11 @@ class TrainEngine:
         loss_forward_backward(bufs, self.sx_dtype, B, Cc, H, W, pred, ld, tgt, m, self.w_map, self.cw, o["base"],
                               o["huber_beta"], o["lam_w"], o["lam_grad"], o["grad_mode"], o["grad_base"], o["multiscale"],
                               o["ms_weight"], o["grad_ds"], dpred, ld, grad_scale, out=row)
+        if self.lam_ev > 0 and want_grad:
+            # training only (the reference's validation loss has no lam_ev term, train.py:262-276); den[0] = sum(mask), global under DP
+            L.check(L.lib().sx_loss_ev_l1(self.sx_dtype, B, Cc, H, W, L.ptr(pred), ld, L.ptr(tgt), L.ptr(m), *self._ev_table.c_args(),
+                                          L.ptr(bufs.den), self.lam_ev, L.ptr(row), L.ptr(dpred), ld, float(grad_scale),
+                                          L.stream_ptr()), "sx_loss_ev_l1")
         if px_local is not None:
             row[3:4].copy_(px_local.reshape(1))
         self.nlog += 1
@@ -342,13 +355,11 @@ def train_unet(
 
     `amp=True` on a GPU selects the bf16 tier (bf16 activations, fp32 accumulation / master weights),
     the reference's autocast semantics; `channels_last` and `cudnn_benchmark` are accepted and have
-    no effect (the kernels are NHWC throughout).  `lam_ev > 0` is not implemented on the device path.
+    no effect (the kernels are NHWC throughout).  `lam_ev > 0` adds the physical-space masked L1 term (sx_loss_ev_l1).
     """
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("train_unet (MI355X build): device must be a CUDA/ROCm device; there is no CPU path")
-    if lam_ev and lam_ev > 0:
-        raise NotImplementedError("train_unet (MI355X build): lam_ev > 0 is not implemented (no caller sets it)")
     if out_ch is None:
         out_ch = 1
     if model_cls is None:
@@ -387,7 +398,7 @@ def train_unet(
     w_map = torch.from_numpy(edge_weights(m0.numpy()[0], sigma_px=3.0))
 
     engine = TrainEngine(model, dtype=torch.bfloat16 if use_amp else torch.float32, lr=lr_init, weight_decay=weight_decay,
-                         clip_grad=clip_grad, channel_weights=cw_list, w_map=w_map,
+                         clip_grad=clip_grad, channel_weights=cw_list, w_map=w_map, lam_ev=lam_ev, norm=norm,
                          loss_opts=dict(lam_w=lam_w, base="huber", huber_beta=0.05, grad_mode="vector", grad_base=grad_base,
                                         multiscale=multiscale, ms_weight=ms_weight, grad_ds=2))
     if ckpt_resume is not None and "opt" in ckpt_resume:
