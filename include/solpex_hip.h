@@ -332,7 +332,9 @@ typedef enum sx_unet_tensor {
   SX_T_DPRED = 4,      /* gradient w.r.t. PRED (same layout), written by the caller */
   SX_T_DSKIP = 5,      /* gradient w.r.t. skip `index` (written by decode backward) */
   SX_T_DBOTTLENECK = 6,
-  SX_T_FILM_DPARAMS = 7 /* fp32 [B][P]: d loss / d params, accumulated by both backward halves */
+  SX_T_FILM_DPARAMS = 7, /* fp32 [B][P]: d loss / d params, accumulated by both backward halves */
+  SX_T_DINPUT = 8        /* gradient w.r.t. the input image x (layout of INPUT), written by sx_unet_encode_backward
+                            when SX_BWD_INPUT_GRAD is set */
 } sx_unet_tensor;
 
 typedef struct sx_view { int64_t offset_bytes; int32_t ld, C, H, W; } sx_view;
@@ -358,6 +360,8 @@ int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const 
                                   inside sx_unet_encode_backward (one launch for all of them); film_dec.* and
                                   decoders.*.net.{1,4}.*, up_convs.*.bias, out.bias gradients are complete only after that call */
 #define SX_BWD_NO_DPARAMS       64 /* skip FILM_DPARAMS (the gradient w.r.t. the FiLM inputs): a training step does not read it */
+#define SX_BWD_INPUT_GRAD      128 /* sx_unet_encode_backward: also back-propagate to the input image (SX_T_DINPUT); the
+                                      reference gets it from autograd when x.requires_grad (models.py:205) */
 #define SX_BWD_ONLY_BOTTLENECK  16 /* sx_unet_encode_backward only: back-propagate the bottleneck block and finish ITS convolution
                                       weight gradients (bot.net.{0,3}.weight, bot.shortcut.weight), then return ...            */
 #define SX_BWD_AFTER_BOTTLENECK 32 /* ... and a second call with this flag does everything else (the encoder levels, every

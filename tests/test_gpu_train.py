@@ -197,7 +197,8 @@ def test_loss_ev_l1_value_and_gradient_match_reference(golden, dtype):
     tdt = torch.bfloat16 if dtype == 1 else torch.float32
     pq = pred.to(tdt).float()                       # what the device sees
     pd = pq.permute(0, 2, 3, 1).contiguous().to(tdt).cuda()
-    dp = torch.full((B, H, W, Cc), 0.25, dtype=tdt, device="cuda")      # the term ADDS to an existing gradient
+    base = 0.25 if dtype == 0 else 0.0              # the term ADDS to an existing gradient (bf16: rounding of the sum would dominate)
+    dp = torch.full((B, H, W, Cc), base, dtype=tdt, device="cuda")
     out = torch.zeros(4, device="cuda")
     den = mask.sum().reshape(1).cuda()
     tab = norm_table(_norm(), Cc)
@@ -208,7 +209,7 @@ def test_loss_ev_l1_value_and_gradient_match_reference(golden, dtype):
     torch.cuda.synchronize()
     if dtype == 0:
         assert abs(float(out[0]) - lam * float(g["ev_loss"])) < 1e-5 * lam * float(g["ev_loss"])
-        got = (dp.float().cpu().permute(0, 3, 1, 2) - 0.25) / (lam * gs)
+        got = (dp.float().cpu().permute(0, 3, 1, 2) - base) / (lam * gs)
         assert rel_err(got, g["ev_grad"]) < 1e-5
     else:
         # bf16 predictions: compare with the oracle on the rounded inputs
@@ -220,8 +221,8 @@ def test_loss_ev_l1_value_and_gradient_match_reference(golden, dtype):
         ref = ((norm_ref.norm_inverse(specs, pr, mask) - norm_ref.norm_inverse(specs, tgt, mask)).abs() * mask).sum() / mask.sum().clamp_min(1e-8)
         ref.backward()
         assert abs(float(out[0]) - lam * float(ref)) < 1e-4 * lam * float(ref)
-        got = (dp.float().cpu().permute(0, 3, 1, 2) - 0.25) / (lam * gs)
-        assert rel_err(got, pr.grad) < 2e-2          # the sum 0.25 + g is stored in bf16
+        got = (dp.float().cpu().permute(0, 3, 1, 2) - base) / (lam * gs)
+        assert rel_err(got, pr.grad) < 1e-2          # stored in bf16
 
 
 def test_train_unet_with_lam_ev_matches_reference_history(golden, tmp_path):

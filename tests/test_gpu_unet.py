@@ -152,6 +152,70 @@ def test_dropout_masks_and_grad_accumulation_against_oracle():
         assert rel_err(prm.grad.cpu(), sdr[k].grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("dtype,tol_p,tol_g", [(torch.float32, 1e-4, 5e-4), (torch.bfloat16, 1e-2, 6e-2)])
+def test_identity_shortcut_and_input_gradient_against_oracle(dtype, tol_p, tol_g):
+    """in_ch == base: the first block's shortcut is nn.Identity (solpex/models.py:73-77: no shortcut.weight in the
+    state_dict); and x.requires_grad: the gradient w.r.t. the input image, which the reference gets from autograd."""
+    from oracle import unet_ref, loss_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.synth import make_batch
+    from unet_amd.losses import masked_weighted_loss
+    cfg = UNetCfg(in_ch=16, out_ch=4, base=16, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=11)
+    assert "encoders.0.shortcut.weight" not in sd and "encoders.1.shortcut.weight" in sd
+    bt = make_batch(3, 24, 16, in_ch=16, out_ch=4, P=5, seed=13, jitter_masks=True)
+    kw = dict(base="huber", huber_beta=0.05, lam_grad=0.0, lam_w=0.0)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, pr = bt["x"].clone().requires_grad_(True), bt["params"].clone().requires_grad_(True)
+    o = unet_ref.unet_forward(sdr, cfg, xr, pr)
+    lr = loss_ref.masked_weighted_loss(o, bt["y"], bt["mask"], **kw)
+    lr.backward()
+    model = build(cfg, sd).train()
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())           # the identity adds nothing to the state_dict
+    model.compute_dtype = dtype
+    x, p = bt["x"].cuda().requires_grad_(True), bt["params"].cuda().requires_grad_(True)
+    pred = model(x, params=p)
+    loss = masked_weighted_loss(pred, bt["y"].cuda(), bt["mask"].cuda(), **kw)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(pred.detach().float().cpu(), o.detach()) < tol_p
+    assert abs(float(loss) - float(lr)) < tol_p * abs(float(lr))
+    assert x.grad is not None and x.grad.shape == x.shape
+    assert rel_err(x.grad.cpu(), xr.grad) < tol_g
+    assert rel_err(p.grad.cpu(), pr.grad) < tol_g
+    gmax = max(float(v.grad.norm()) for v in sdr.values())
+    for k, q in model.named_parameters():
+        ref = sdr[k].grad
+        err = float((q.grad.cpu().double() - ref.double()).norm())
+        assert err < tol_g * max(float(ref.norm()), 0.05 * gmax), (str(dtype), k, err, float(ref.norm()))
+
+
+def test_identity_shortcut_train_engine_step():
+    """TrainEngine with an identity first shortcut: the constant identity weight is no parameter (not in the arena, not
+    stepped), the step matches the oracle's gradients."""
+    from oracle import unet_ref, loss_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.synth import make_batch
+    from unet_amd.train import TrainEngine
+    cfg = UNetCfg(in_ch=8, out_ch=8, base=8, P=0, depth=2)
+    sd = init_state_dict(cfg, seed=17)
+    bt = make_batch(4, 16, 16, in_ch=8, out_ch=8, P=0, seed=19, jitter_masks=True)
+    opts = dict(lam_w=0.0, lam_grad=0.0, base="huber", huber_beta=0.05, multiscale=0, grad_ds=1)
+    model = build(cfg, sd).train()
+    eng = TrainEngine(model, dtype=torch.float32, lr=1e-3, clip_grad=0.0, loss_opts=opts)
+    assert sum(k for _, k in eng.slots.values()) == sum(v.numel() for v in sd.values())
+    out = eng.train_step(bt["x"].cuda(), bt["y"].cuda(), bt["mask"].cuda(), None, lam_grad=0.0)
+    torch.cuda.synchronize()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lr = loss_ref.masked_weighted_loss(unet_ref.unet_forward(sdr, cfg, bt["x"], None), bt["y"], bt["mask"], lam_w=0.0, lam_grad=0.0,
+                                       base="huber", huber_beta=0.05)
+    lr.backward()
+    assert abs(float(out[0]) - float(lr)) < 1e-4 * abs(float(lr))
+    for k, q in model.named_parameters():
+        assert rel_err(q.grad.cpu(), sdr[k].grad) < 5e-4, k
+    assert torch.equal(model._identity_shortcut.cpu().view(8, 8), torch.eye(8))
+
+
 def test_errors_and_boundaries():
     from unet_amd.models import UNet
     m = UNet(in_ch=1, out_ch=8, base=8, P=5, depth=2)

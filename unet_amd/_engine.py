@@ -102,7 +102,7 @@ class UNetSession:
             ld, Cc, H, W = vw.ld, vw.C, vw.H, vw.W
             # the view may be a channel slice of a wider buffer: build it from the base with as_strided
             base = self.ws[vw.offset_bytes:].view(self.tdtype)
-            Cv = ld if (padded and which in (L.SX_T_PRED, L.SX_T_DPRED, L.SX_T_INPUT)) else Cc
+            Cv = ld if (padded and which in (L.SX_T_PRED, L.SX_T_DPRED, L.SX_T_INPUT, L.SX_T_DINPUT)) else Cc
             t = base.as_strided((self.B, Cv, H, W), (H * W * ld, 1, W * ld, ld))
         self._views[key] = t
         return t.view(t.shape) if fresh else t

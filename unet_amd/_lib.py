@@ -16,9 +16,9 @@ SX_F32, SX_BF16 = 0, 1
 SX_CONV3, SX_CONV1, SX_CONVT_FWD, SX_CONVT_BWD = 0, 1, 2, 3
 SX_ERR_INVALID, SX_ERR_UNSUPPORTED, SX_ERR_HIP = -1, -2, -3
 (SX_T_INPUT, SX_T_SKIP, SX_T_BOTTLENECK, SX_T_PRED, SX_T_DPRED, SX_T_DSKIP, SX_T_DBOTTLENECK,
- SX_T_FILM_DPARAMS) = range(8)
+ SX_T_FILM_DPARAMS, SX_T_DINPUT) = range(9)
 SX_BWD_WEIGHT_GRADS, SX_BWD_ACCUMULATE, SX_BWD_ZERO_DPARAMS, SX_BWD_DEFER_FILM = 1, 2, 4, 8
-SX_BWD_ONLY_BOTTLENECK, SX_BWD_AFTER_BOTTLENECK, SX_BWD_NO_DPARAMS = 16, 32, 64
+SX_BWD_ONLY_BOTTLENECK, SX_BWD_AFTER_BOTTLENECK, SX_BWD_NO_DPARAMS, SX_BWD_INPUT_GRAD = 16, 32, 64, 128
 SX_NORM_LOG, SX_NORM_LINEAR, SX_NORM_SYMLOG = 0, 1, 2
 SX_WGRAD_STATIC_BYTES = 32 << 20
 SX_GN_BWD_SUMS_READY = 4

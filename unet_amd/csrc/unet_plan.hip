@@ -139,7 +139,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   // gradient w.r.t. block inputs
   for (int k = 0; k < n_blocks; ++k) {
     BlockBuf& b = p.blk[k];
-    if (k == 0) { b.dX = -1; b.dx_ld = 0; }
+    if (k == 0) { b.dX = take((int64_t)B * b.H * b.W * p.in_pad * p.esz); b.dx_ld = p.in_pad; }   // d(input image), SX_BWD_INPUT_GRAD
     else if (k <= D) { b.dX = take((int64_t)B * b.H * b.W * b.Cin * p.esz); b.dx_ld = b.Cin; }   // = d(pool_{k-1})
     else { const int l = D - 1 - (k - D - 1); b.dX = p.dcat[l]; b.dx_ld = 2 * p.C[l]; }
   }
@@ -461,6 +461,7 @@ extern "C" int sx_unet_view(const sx_unet_desc* d, int which, int index, sx_view
       SX_REQUIRE(index >= 0 && index < D, "sx_unet_view: dskip index %d", index);
       set(p.dcat[index] + (int64_t)p.C[index] * p.esz, 2 * p.C[index], p.C[index], index); break;
     case SX_T_DBOTTLENECK: set(p.blk[D].dO, p.C[D], p.C[D], D); break;
+    case SX_T_DINPUT: set(p.blk[0].dX, p.in_pad, d->in_ch, 0); break;
     case SX_T_FILM_DPARAMS: out->offset_bytes = p.dparams; out->ld = d->P; out->C = d->P; out->H = 1; out->W = 1; break;
     default: set_error("sx_unet_view: unknown tensor %d", which); return SX_ERR_INVALID;
   }
@@ -668,7 +669,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     const BlockBuf& nxt = p.blk[l + 1];   // its dX is d(pool_l)
     SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
                                     at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
-    SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0, flags, wq, st));
+    SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0 || (flags & SX_BWD_INPUT_GRAD), flags, wq, st));
   }
   if (wg && (flags & SX_BWD_DEFER_FILM))
     for (int k = D + 1; k <= 2 * D; ++k) {       // decoder blocks: their per-sample sums are still in the workspace

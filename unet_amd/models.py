@@ -142,9 +142,11 @@ class _EncodeFn(torch.autograd.Function):
         for l in range(D):
             _put(sess.view(L.SX_T_DSKIP, l), dskips[l])
         want_w = any(ctx.needs_input_grad[4:])
-        flags = L.SX_BWD_ZERO_DPARAMS | (L.SX_BWD_WEIGHT_GRADS if want_w else 0)
+        want_x = ctx.needs_input_grad[2]
+        flags = L.SX_BWD_ZERO_DPARAMS | (L.SX_BWD_WEIGHT_GRADS if want_w else 0) | (L.SX_BWD_INPUT_GRAD if want_x else 0)
         gviews = owner._grad_views(sess) if want_w else None
         sess.encode_backward(ctx.film_params, flags)
+        dx = sess.view(L.SX_T_DINPUT).float().contiguous() if want_x else None
         dparams = None
         if ctx.film_params is not None and ctx.needs_input_grad[3]:
             dparams = sess.view(L.SX_T_FILM_DPARAMS).clone()
@@ -154,7 +156,7 @@ class _EncodeFn(torch.autograd.Function):
             for k, i in enumerate(enc_idx):
                 if ctx.needs_input_grad[4 + k]:
                     wgrads[k] = gviews[i]
-        return (None, None, None, dparams, *wgrads)
+        return (None, None, dx, dparams, *wgrads)
 
 
 class _DecodeFn(torch.autograd.Function):
@@ -242,13 +244,23 @@ class UNet(nn.Module):
         self._dec_idx = [i for i, m in enumerate(mask) if not m]
         self._wcache = {}
         self._wgen = 0
+        # in_ch == base makes the first block's shortcut an nn.Identity (reference: solpex/models.py:73-77): no parameter, no
+        # state_dict entry.  The fused block kernels always run a 1x1 shortcut GEMM next to conv1, so the identity is fed to
+        # them as a constant identity-matrix weight (exact in bf16 and fp32); its "gradient" is discarded.
+        self._const_names = []
         if in_ch == base:
-            raise ValueError("UNet (HIP): in_ch == base makes the first shortcut an Identity, which the fused "
-                             "block kernels do not cover")
+            self.register_buffer("_identity_shortcut", torch.eye(base, dtype=torch.float32).view(base, base, 1, 1).contiguous(),
+                                 persistent=False)
+            self._const_names.append("encoders.0.shortcut.weight")
 
     # ------------------------------------------------------------------ plumbing
+    def _const_tensors(self):
+        """Structural constants that sit in the kernels' parameter table but are no parameters of the module."""
+        return {n: self._identity_shortcut for n in self._const_names}
+
     def _ordered_params(self):
         named = dict(self.named_parameters())
+        named.update(self._const_tensors())
         return [named[n] for n in self._names]
 
     def _pick_dtype(self):
@@ -299,8 +311,6 @@ class UNet(nn.Module):
             raise RuntimeError("UNet (HIP): inputs must be CUDA (ROCm) tensors; this build has no CPU path")
         if x.dim() != 4 or x.shape[1] != self._cfg["in_ch"]:
             raise ValueError(f"UNet (HIP): expected input (B,{self._cfg['in_ch']},H,W), got {tuple(x.shape)}")
-        if x.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("UNet (HIP): gradients w.r.t. the input image are not implemented")
         return x if x.dtype == torch.float32 else x.float()
 
     def _film_params(self, params, B):

@@ -82,9 +82,11 @@ class TrainEngine:
         # part of the encoder half (SX_BWD_ONLY_BOTTLENECK); their all-reduce overlaps the encoder levels' backward
         def botw(n):
             return n in ("bot.net.0.weight", "bot.net.3.weight", "bot.shortcut.weight")
+        const = model._const_tensors()           # table entries that are no parameters (identity shortcut): not in the arena
         dec = [names[i] for i in model._dec_idx if not late(names[i])]
         bot = [names[i] for i in model._enc_idx if botw(names[i])]
-        enc = [names[i] for i in model._dec_idx if late(names[i])] + [names[i] for i in model._enc_idx if not botw(names[i])]
+        enc = ([names[i] for i in model._dec_idx if late(names[i])] +
+               [names[i] for i in model._enc_idx if not botw(names[i]) and names[i] not in const])
         self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + bot + enc)
         model._wgen += 1
         self.n_dec = self.slots[(bot + enc)[0]][0] if (bot + enc) else self.flat_p.numel()
@@ -93,8 +95,9 @@ class TrainEngine:
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_count = 0
         named = dict(model.named_parameters())
-        self.params = [named[n] for n in names]
-        self.grads = [named[n].grad for n in names]
+        self._const_grads = {n: torch.zeros_like(t) for n, t in const.items()}      # scratch the kernels may write
+        self.params = [named[n] if n in named else const[n] for n in names]
+        self.grads = [named[n].grad if n in named else self._const_grads[n] for n in names]
         self.cw = _prep_cw(channel_weights, self.cfg["out_ch"], self.device)
         self.w_map = None if w_map is None else w_map.to(self.device, torch.float32).reshape(w_map.shape[-2], w_map.shape[-1]).contiguous()
         self.loss_opts = dict(lam_grad=0.2, lam_w=1.0, base="huber", huber_beta=0.05, grad_mode="vector", grad_base="l1",
