@@ -152,6 +152,8 @@ def test_load_checkpoint_depth3_round_trip(tmp_path):
     assert all(np.isfinite(v).all() for v in hist.values()) and hist["va_mse"][0] <= 5.0    # the reference's smoke bound
     m2, norm2, (mu, std), pt, pk = load_checkpoint(path, "cuda")
     assert pk == ["a", "b", "c", "d", "e"] and pt is None and mu.shape == (5,)
+    # the reference's resume path (train.py:117-118) loads ckpt["scaler"] into an ENABLED GradScaler when amp is on
+    torch.amp.GradScaler("cuda", enabled=True).load_state_dict(torch.load(path, weights_only=False)["scaler"])
     out = predict_fields(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy())
     te = predict_te(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy())
     assert out.shape == (8, 32, 16) and np.isfinite(out).all()
@@ -252,3 +254,32 @@ def test_train_unet_with_lam_ev_matches_reference_history(golden, tmp_path):
     fin = model.state_dict()
     for k in ("out.weight", "encoders.0.net.0.weight"):
         assert rel_err(fin[k].cpu(), g["ev_final::" + k]) < 2e-3, k
+
+
+def test_optimizer_skips_parameters_without_gradients():
+    """Like torch's AdamW with grad None: z_proj / z_unproj (never touched by the kernels) and, for a step without `params`, the
+    FiLM generators are neither decayed nor stepped, and get no optimizer state in the checkpoint."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.synth import make_batch
+    m = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2, z_dim=4).cuda().train()
+    eng = TrainEngine(m, dtype=torch.float32, lr=1e-2, weight_decay=0.1, clip_grad=1.0)
+    assert eng.n_bot <= eng.n_film < eng.n_kernel < eng.flat_p.numel()
+    bt = {k: v.cuda() for k, v in make_batch(2, 16, 16, seed=4, jitter_masks=True).items()}
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    eng.train_step(bt["x"], bt["y"], bt["mask"], None, lam_grad=0.0)            # unconditioned step
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        same = torch.equal(p.detach(), before[n])
+        if n.startswith(("film_", "z_proj", "z_unproj")):
+            assert same, n
+        elif ".weight" in n and "net.0" in n:
+            assert not same, n
+    eng.train_step(bt["x"], bt["y"], bt["mask"], bt["params"], lam_grad=0.0)    # conditioned: FiLM generators move now
+    torch.cuda.synchronize()
+    assert not torch.equal(m.film_bot.net[0].weight.detach(), before["film_bot.net.0.weight"])
+    assert torch.equal(m.z_proj.weight.detach(), before["z_proj.weight"])
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+    eng.export_opt_state(opt)
+    assert m.z_proj.weight not in opt.state and m.film_bot.net[0].weight in opt.state

@@ -87,10 +87,20 @@ class TrainEngine:
         bot = [names[i] for i in model._enc_idx if botw(names[i])]
         enc = ([names[i] for i in model._dec_idx if late(names[i])] +
                [names[i] for i in model._enc_idx if not botw(names[i]) and names[i] not in const])
+        # arena tail: every FiLM generator (gradients exist only when the step is conditioned), then parameters the kernels
+        # never produce gradients for (z_proj / z_unproj).  The reference's optimizer skips parameters whose grad is None:
+        # the clip norm and AdamW run over the arena prefix that got gradients this step (no decay of the rest)
+        film = [n for n in enc if n.startswith("film_")]
+        enc = [n for n in enc if not n.startswith("film_")] + film
         self.flat_p, self.flat_g, self.slots = flatten_parameters(model, order=dec + bot + enc)
         model._wgen += 1
         self.n_dec = self.slots[(bot + enc)[0]][0] if (bot + enc) else self.flat_p.numel()
         self.n_bot = self.slots[enc[0]][0] if enc else self.flat_p.numel()
+        owned = set(dec + bot + enc)
+        rest = [n for n, _ in model.named_parameters() if n not in owned]
+        self.n_kernel = self.slots[rest[0]][0] if rest else self.flat_p.numel()       # end of the kernel-owned parameters
+        self.n_film = self.slots[film[0]][0] if film else self.n_kernel               # start of the FiLM generators
+        self._film_pending = False
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_count = 0
@@ -234,14 +244,18 @@ class TrainEngine:
                 if h_bot is not None:
                     h_bot.wait()
                 h_enc.wait()
-            self.optimizer_step(lr)
+            self.optimizer_step(lr, n=self.n_kernel if (fp is not None or self._film_pending) else self.n_film)
+            self._film_pending = False
+        elif fp is not None:
+            self._film_pending = True            # an accumulation window with at least one conditioned step has FiLM gradients
         return out
 
-    def optimizer_step(self, lr=None):
-        """clip_grad_norm_ + AdamW over the flat arena (reference: solpex/train.py:226-233)."""
+    def optimizer_step(self, lr=None, n=None):
+        """clip_grad_norm_ + AdamW over the flat arena (reference: solpex/train.py:226-233); `n`: arena prefix that holds
+        gradients (default: every kernel-owned parameter)."""
         lib = L.lib()
         self.step_count += 1
-        n = self.flat_p.numel()
+        n = self.n_kernel if n is None else int(n)
         use_clip = bool(self.clip and self.clip > 0)
         cur, nxt = self._ss[self.step_count & 1:], self._ss[(self.step_count + 1) & 1:]
         if use_clip:
@@ -259,7 +273,8 @@ class TrainEngine:
         if self.accum > 0:
             if self.dp:
                 sxdist.all_reduce_sum(self.flat_g)
-            self.optimizer_step(lr)
+            self.optimizer_step(lr, n=self.n_kernel if self._film_pending else self.n_film)
+            self._film_pending = False
 
     @torch.no_grad()
     def eval_step(self, x, y, mask, params=None, *, lam_grad=None, norm=None, err_acc=None):
@@ -306,6 +321,8 @@ class TrainEngine:
         """Fill a torch.optim.AdamW's state with views of the engine's moments (checkpoint format parity)."""
         for n, p in self.model.named_parameters():
             o, k = self.slots[n]
+            if o >= self.n_kernel:           # never stepped (no gradient): the reference's optimizer holds no state for it
+                continue
             opt.state[p] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": self.flat_m[o:o + k].view(p.shape), "exp_avg_sq": self.flat_v[o:o + k].view(p.shape)}
 
@@ -384,7 +401,9 @@ def train_unet(
                                                            threshold=lr_threshold, threshold_mode="rel", cooldown=0,
                                                            min_lr=lr_min, eps=1e-8)
     use_amp = bool(amp)
-    scaler = torch.amp.GradScaler("cuda", enabled=False)     # bf16 needs no loss scaling; key kept in the checkpoint
+    # bf16 needs no loss scaling: nothing here scales.  The object only provides the checkpoint's "scaler" entry in the form
+    # the reference's resume path loads (train.py:117-118 calls scaler.load_state_dict when amp is on: an enabled scaler's dict)
+    scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
 
     start_epoch, best_val = 0, float("inf")
     ckpt_resume = None
