@@ -9,4 +9,7 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/$tag -- p
 db=$(find $root/gpurun_out/$tag -name "*_results.db" | head -1)
 python3 $root/tools/prof_summary.py $db 25 > $root/gpurun_out/${tag}_kernels.txt
 python3 $root/tools/prof_cats.py $db 25 > $root/gpurun_out/${tag}_families.txt
+n=$(python3 -c "import sqlite3,sys; print(sqlite3.connect(sys.argv[1]).execute('select count(*) from kernels').fetchone()[0])" $db)
+per=$((n / 25))
+python3 $root/tools/prof_seq.py $db $((n - per - 2)) $((per + 4)) > $root/gpurun_out/${tag}_sequence.txt
 rm -rf $root/gpurun_out/$tag
