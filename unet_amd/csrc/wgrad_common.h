@@ -43,7 +43,9 @@ struct WgWsArgs {
 // A prepared problem of the persistent bf16 tier: kernel arguments, instantiation code, grid and dynamic LDS.
 struct WgWsLaunch { WgWsArgs a; int variant, blocks, smem; };
 int wgrad_ws_prepare(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual = 0);
+                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual = 0, int batched = 1);
+// batched: the problem will share a launch with others (fewer, longer splits: it need not fill the chip alone); the slab
+// never exceeds wgrad_ws_slab_bytes(), which sizes for the stand-alone plan
 int wgrad_ws_launch(const WgWsLaunch* l, int n, hipStream_t st);
 
 // Persistent bf16 tier.  slab bytes it needs (0 = shape not covered) / launch (0 = launched, 1 = not covered, <0 error).

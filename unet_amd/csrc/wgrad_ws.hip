@@ -398,8 +398,13 @@ struct WgWsPlan {
 
 // tuning knobs, read once per process
 static int wg_min_tiles(bool ct) { static const int v = env_int("SX_WG_MIN_TILES", 0); return v > 0 ? v : (ct ? 4 : 8); }
+// blocks one problem aims for (S * R).  Problems run many to a launch (wgrad_ws_launch), so none of them has to fill the
+// 256 CUs alone: fewer, longer splits mean fewer slabs to write and to reduce
+// (measured on cfg A, batch 64: 256 blocks per problem 1.906 ms/step, 128: 1.846, 64: 1.807, 32: 1.820, 16: 1.97); a problem
+// launched on its own (sx_conv_wgrad) still spreads over the whole chip
+static int wg_target_blocks(bool batched) { static const int v = env_int("SX_WG_TARGET", 0); return batched ? (v > 0 ? v : 64) : 256; }
 
-static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
+static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb, bool batched = false) {
   WgWsPlan p;
   memset(&p, 0, sizeof(p));
   if (mode != SX_CONV3 && mode != SX_CONV1 && mode != SX_CONVT_FWD) return p;
@@ -427,7 +432,7 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb) {
   // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
   p.tg_count = 1;
   p.R = p.a_tiles * p.b_tiles;
-  int S = std::max(1, std::min(std::max(1, p.ntiles / wg_min_tiles(ct)), 256 / p.R));
+  int S = std::max(1, std::min(std::max(1, p.ntiles / wg_min_tiles(ct)), std::max(1, wg_target_blocks(batched) / p.R)));
   p.tiles_per_split = cdiv(p.ntiles, S);
   p.S = cdiv(p.ntiles, p.tiles_per_split);
   p.slab_bytes = (int64_t)p.S * p.taps * p.CaPad * p.CbPad * 4;
@@ -471,8 +476,8 @@ int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
 
 // 0 = prepared (launch with wgrad_ws_launch), 1 = shape not covered
 int wgrad_ws_prepare(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
-                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual) {
-  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
+                     float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual, int batched) {
+  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb, batched != 0);
   if (!p.ok) return 1;
   if (dual && (mode != SX_CONV3 || p.MI != 4 || (p.NBF != 4 && p.NBF != 1) || p.a_tiles != 1 || p.b_tiles != 1 || p.TWL != 4 || Ca != 64)) return 1;
   WgWsArgs& a = out->a;
@@ -519,7 +524,7 @@ int wgrad_ws_launch(const WgWsLaunch* l, int n, hipStream_t st) {
 int wgrad_ws_try(int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
                  float* slab, WgReduceDesc* desc, hipStream_t st, int dual) {
   WgWsLaunch l;
-  const int rc = wgrad_ws_prepare(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, slab, desc, &l, dual);
+  const int rc = wgrad_ws_prepare(mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, slab, desc, &l, dual, 0);
   if (rc != 0) return rc;
   return wgrad_ws_launch(&l, 1, st);
 }
