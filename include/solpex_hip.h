@@ -281,6 +281,10 @@ int sx_loss_ev_l1(int dtype, int B, int C, int H, int W, const void* pred, int p
  * Optimizer (train.py:82,226-233): grad-norm, clip_grad_norm_, AdamW over one flat fp32 arena.
  * --------------------------------------------------------------------------------------------- */
 int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
+/* The first half of sx_grad_sumsq alone (deterministic block partials left on the device; returns their count, >= 1):
+ * follow it, on the same stream, with sx_adamw_step(gnorm_sq = NULL, max_norm > 0, same g and n), whose blocks add the
+ * partials themselves in a fixed order -- clip_grad_norm_ + AdamW in two launches instead of three. */
+int sx_grad_sumsq_partial(const float* g, int64_t n, void* stream);
 int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float max_norm,
                   const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream);

@@ -80,8 +80,10 @@ struct PackDesc {
   int64_t total;
 };
 static constexpr int PACK_MAX = 56;
-struct PackArgs { PackDesc d[PACK_MAX]; int n; };
+// pad: optional zero-padded fp32 copy out[i] = i < n ? src[i] : 0 for i < npad <= 256 (the head's bias), done by block 0
+struct PackPad { const float* src; float* dst; int n, npad; };
+struct PackArgs { PackDesc d[PACK_MAX]; int n; PackPad pad; };
 int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d);
-int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st);
+int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad = nullptr);
 
 }  // namespace sx

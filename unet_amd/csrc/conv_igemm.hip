@@ -197,6 +197,8 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
 // out[tap][row][k] for every layer of a descriptor table (one launch packs the whole network)
 template <typename T>
 __global__ void pack_weight_kernel(PackArgs A) {
+  if (blockIdx.x == 0 && A.pad.dst && (int)threadIdx.x < A.pad.npad)
+    A.pad.dst[threadIdx.x] = (int)threadIdx.x < A.pad.n ? A.pad.src[threadIdx.x] : 0.f;
   int di = 0;
   while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
   const PackDesc& D = A.d[di];
@@ -344,7 +346,7 @@ int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int 
   return SX_OK;
 }
 
-int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st) {
+int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad) {
   // adjacent (forward, transposed) descriptors of the same 3x3 / 1x1 weight go through the tile kernel, one read for both
   std::vector<PackDesc> rest;
   std::vector<PackPair> pairs;
@@ -380,14 +382,19 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st) 
   }
   descs = rest.data();
   n = (int)rest.size();
+  PackDesc nothing;
+  memset(&nothing, 0, sizeof(nothing));
+  if (n == 0 && pad) { descs = &nothing; n = 1; }       // the padded copy still needs its launch
   for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
     PackArgs A;
+    memset(&A.pad, 0, sizeof(A.pad));
+    if (pad && i0 == 0) A.pad = *pad;
     A.n = std::min(PACK_MAX, n - i0);
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
       A.d[i] = descs[i0 + i];
       A.d[i].blk0 = blk;
-      A.d[i].nblk = (int)std::min<int64_t>(cdiv64(A.d[i].total, 256), 256);
+      A.d[i].nblk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(A.d[i].total, 256), 256));
       blk += A.d[i].nblk;
     }
     if (dtype == SX_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blk), dim3(256), 0, st, A);

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void prepare1_kernel(const float* __restrict__
 }
 
 // den[0..2] = sums of the n partial triples (fixed order: thread t adds entries t, t + 256, ...; then a tree); den[3..8] = 0
-__global__ __launch_bounds__(256) void den_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ den) {
+__global__ __launch_bounds__(256) void den_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ den, float* __restrict__ num) {
+  for (int i = threadIdx.x; i < NSLOT * SLOT_STRIDE; i += blockDim.x) num[i] = 0.f;   // phase 2's numerator slots start at zero
   float v[3] = {0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < n; i += blockDim.x) { v[0] += part[i * 4]; v[1] += part[i * 4 + 1]; v[2] += part[i * 4 + 2]; }
   __shared__ float red[12];
@@ -419,8 +420,46 @@ __global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
   }
 }
 
+struct FinalArgs {
+  const float* den; float* num; const float* cw; int C;
+  int nscales; float lam_w, lam_grad, ms_weight; int has_w;
+  float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = out[3] = sum m (scale 0)
+};
+// One block: total the numerator slots (fixed order), write out[0..3], and leave the slots ZERO for the next call (the
+// single-scale path has no memset launch: sx_loss_prepare's reduction kernel zeroes them the first time).
+__device__ __forceinline__ void loss_final_block(const FinalArgs& a) {
+  __shared__ float tot[16];
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int sl = 0; sl < NSLOT; ++sl) t += a.num[sl * SLOT_STRIDE + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NSLOT * SLOT_STRIDE; i += blockDim.x) a.num[i] = 0.f;
+  if (threadIdx.x) return;
+  const float scw = cw_sum(a.cw, a.C);
+  float loss = 0.f;
+  for (int s = 0; s < a.nscales; ++s) {
+    const float coef = s == 0 ? 1.f : (s == 1 ? a.ms_weight : 0.5f * a.ms_weight);
+    float L = tot[s * 4 + 0] / fmaxf(a.den[s * 3 + 0] * scw, 1e-8f);
+    if (a.has_w && a.lam_w != 0.f) L += a.lam_w * (tot[s * 4 + 1] / fmaxf(a.den[s * 3 + 1] * scw, 1e-8f));
+    if (a.lam_grad != 0.f) L += a.lam_grad * (tot[s * 4 + 3] / fmaxf(a.den[s * 3 + 2] * scw, 1e-8f));
+    loss += coef * L;
+  }
+  a.out[0] = loss;
+  a.out[1] = tot[2];
+  a.out[2] = a.den[0];
+  a.out[3] = a.den[0];   // a DP caller overwrites this with its local pixel count (den is all-reduced by then)
+}
+__global__ void loss_final_kernel(FinalArgs a) {
+  if (blockIdx.x == 0) loss_final_block(a);
+}
+
 template <typename T, bool FAST>
-__global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a) {
+__global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin) {
+  // the numerators are complete (base_pool and sobel_fwd ran before this launch): block 0 finishes the loss value here
+  // instead of a one-block launch of its own
+  if (blockIdx.x == 0) loss_final_block(fin);
   constexpr int MC = FAST ? 8 : FUSE_MAXC;
   const int k = FAST ? 2 : a.k;
   const int gh = a.H / k, gw = a.W / k, hw = a.H * a.W;
@@ -502,34 +541,6 @@ __global__ void unpool2_add_kernel(const float* __restrict__ coarse, float* __re
   }
 }
 
-struct FinalArgs {
-  const float* den; const float* num; const float* cw; int C;
-  int nscales; float lam_w, lam_grad, ms_weight; int has_w;
-  float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = out[3] = sum m (scale 0)
-};
-__global__ void loss_final_kernel(FinalArgs a) {
-  __shared__ float tot[16];
-  if (threadIdx.x < 16) {
-    float t = 0.f;
-    for (int sl = 0; sl < NSLOT; ++sl) t += a.num[sl * SLOT_STRIDE + threadIdx.x];
-    tot[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x || blockIdx.x) return;
-  const float scw = cw_sum(a.cw, a.C);
-  float loss = 0.f;
-  for (int s = 0; s < a.nscales; ++s) {
-    const float coef = s == 0 ? 1.f : (s == 1 ? a.ms_weight : 0.5f * a.ms_weight);
-    float L = tot[s * 4 + 0] / fmaxf(a.den[s * 3 + 0] * scw, 1e-8f);
-    if (a.has_w && a.lam_w != 0.f) L += a.lam_w * (tot[s * 4 + 1] / fmaxf(a.den[s * 3 + 1] * scw, 1e-8f));
-    if (a.lam_grad != 0.f) L += a.lam_grad * (tot[s * 4 + 3] / fmaxf(a.den[s * 3 + 2] * scw, 1e-8f));
-    loss += coef * L;
-  }
-  a.out[0] = loss;
-  a.out[1] = tot[2];
-  a.out[2] = a.den[0];
-  a.out[3] = a.den[0];   // a DP caller overwrites this with its local pixel count (den is all-reduced by then)
-}
 
 // ---------------------------------------------------------------- workspace layout (floats)
 struct LossLayout {
@@ -602,7 +613,7 @@ extern "C" int sx_loss_prepare(int B, int C, int H, int W, const float* mask, co
     const int rows_per = cdiv(cdiv(H, chunks), k) * k;
     chunks = cdiv(H, rows_per);
     hipLaunchKernelGGL(prepare1_kernel, dim3(chunks, B), dim3(256), 0, st, mask, w, H, W, k, want_mg ? 1 : 0, ws + L.MG[0], ws + L.PART, rows_per);
-    hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(256), 0, st, ws + L.PART, B * chunks, den);
+    hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(256), 0, st, ws + L.PART, B * chunks, den, ws + L.NUM);
     SX_LAUNCH_CHECK("loss_prepare");
     return SX_OK;
   }
@@ -650,8 +661,6 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
   LossLayout L = loss_layout(B, C, H, W, multiscale, grad_ds);
   float* ws = (float*)workspace;
   float* num = ws + L.NUM;
-  hipError_t e = hipMemsetAsync(num, 0, NSLOT * SLOT_STRIDE * sizeof(float), st);
-  if (e != hipSuccess) return hip_fail(e, "memset(num)");
   const bool want_grad = d_pred != nullptr;
   if (L.ns == 1 && lam_grad != 0.f && L.gds[0] > 1 && H % L.gds[0] == 0 && W % L.gds[0] == 0 && C <= FUSE_MAXC &&
       (!want_grad || dpred_ld % 8 == 0)) {
@@ -667,14 +676,17 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
     const bool fast = gd == 2 && C <= 8 && pred_ld == 8 && (!want_grad || dpred_ld == 8) && W % 2 == 0 &&
                       ((uintptr_t)target % 8) == 0 && ((uintptr_t)mask % 8) == 0 && (!w || ((uintptr_t)w % 8) == 0) &&
                       ((uintptr_t)pred % 16) == 0 && (!want_grad || ((uintptr_t)d_pred % 16) == 0);
-#define SX_FUSE_LAUNCH(KERN)                                                                                    \
+    FinalArgs f;
+    f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = 1; f.lam_w = lam_w; f.lam_grad = lam_grad;
+    f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
+#define SX_FUSE_LAUNCH(KERN, ...)                                                                               \
     do {                                                                                                        \
-      if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(nwin)), dim3(256), 0, st, fa);   \
-                              else hipLaunchKernelGGL((KERN<bf16, false>), dim3(gsz(nwin)), dim3(256), 0, st, fa); }     \
-      else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(nwin)), dim3(256), 0, st, fa);                   \
-             else hipLaunchKernelGGL((KERN<float, false>), dim3(gsz(nwin)), dim3(256), 0, st, fa); }                     \
+      if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__);   \
+                              else hipLaunchKernelGGL((KERN<bf16, false>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__); }     \
+      else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__);                   \
+             else hipLaunchKernelGGL((KERN<float, false>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__); }                     \
     } while (0)
-    SX_FUSE_LAUNCH(base_pool_kernel);
+    SX_FUSE_LAUNCH(base_pool_kernel, fa);
     SobelArgs sa;
     sa.p = ws + L.PG[0]; sa.t = ws + L.TG[0]; sa.m = ws + L.MG[0]; sa.cw = cw;
     sa.ux = want_grad ? ws + L.UX[0] : nullptr; sa.uy = want_grad ? ws + L.UY[0] : nullptr;
@@ -683,17 +695,17 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
     sa.den = den; sa.cgl = lam_grad;
     hipLaunchKernelGGL(sobel_fwd_kernel, dim3(gsz(ng)), dim3(256), 0, st, sa);
     if (want_grad) {
-      SX_FUSE_LAUNCH(grad_out_kernel);
+      SX_FUSE_LAUNCH(grad_out_kernel, fa, f);          // block 0 also finishes the loss value
+    } else {
+      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
     }
 #undef SX_FUSE_LAUNCH
-    FinalArgs f;
-    f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = 1; f.lam_w = lam_w; f.lam_grad = lam_grad;
-    f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
     SX_LAUNCH_CHECK("loss_forward_backward");
     return SX_OK;
   }
   {
+    hipError_t e = hipMemsetAsync(num, 0, NSLOT * SLOT_STRIDE * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "memset(num)");
     const int64_t n = (int64_t)B * C * H * W;
     if (dtype == SX_BF16) hipLaunchKernelGGL(to_planar_kernel<bf16>, dim3(gsz(n)), dim3(256), 0, st, (const bf16*)pred, pred_ld, ws + L.P[0], B, C, H, W);
     else hipLaunchKernelGGL(to_planar_kernel<float>, dim3(gsz(n)), dim3(256), 0, st, (const float*)pred, pred_ld, ws + L.P[0], B, C, H, W);

@@ -11,11 +11,20 @@ namespace sx {
 // so the partials are summed in a fixed order by a second one-block launch instead of racing on an atomic.
 static __device__ float g_sumsq_part[256];
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(int nparts, float* __restrict__ out) {
+// fixed-order sum of the block partials; every thread of the calling block gets the total (same bits in every block)
+__device__ __forceinline__ float sumsq_total(int nparts) {
   float v[1] = {(int)threadIdx.x < nparts ? g_sumsq_part[threadIdx.x] : 0.f};
   __shared__ float red[4];
+  __shared__ float tot;
   block_sum<1>(v, red);
-  if (threadIdx.x == 0) out[0] += v[0];
+  if (threadIdx.x == 0) tot = v[0];
+  __syncthreads();
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int nparts, float* __restrict__ out) {
+  const float t = sumsq_total(nparts);
+  if (threadIdx.x == 0) out[0] += t;
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n) {
@@ -37,6 +46,7 @@ struct AdamArgs {
   float max_norm; const float* gnorm_sq; float grad_mul;
   float* gnorm_out;
   float* clear_after;
+  int fused_parts;      // > 0: the norm comes from the block partials sx_grad_sumsq_partial left on this device (no gnorm_sq)
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float gmul) {
@@ -50,8 +60,11 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   float gmul = a.grad_mul;
-  if (a.gnorm_sq) {
-    const float norm = sqrtf(a.gnorm_sq[0]) * fabsf(a.grad_mul);
+  if (a.gnorm_sq || a.fused_parts > 0) {
+    // fused: every block adds the partials itself, in the same fixed order -> the same clip factor everywhere, and no
+    // one-block launch in between
+    const float ss = a.fused_parts > 0 ? sumsq_total(a.fused_parts) : a.gnorm_sq[0];
+    const float norm = sqrtf(ss) * fabsf(a.grad_mul);
     if (a.max_norm > 0.f) gmul *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
     if (a.gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) a.gnorm_out[0] = norm;
   }
@@ -80,10 +93,22 @@ using namespace sx;
 
 // out[0] += sum g^2 (caller zeroes out).  Deterministic: fixed grid, fixed-order sums.  Calls that overlap on one device
 // (different streams) race on the partials scratch.
+static int sumsq_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 256)); }
+
+// sx_grad_sumsq's first half alone: leaves the block partials on the device for sx_adamw_step(gnorm_sq = NULL, max_norm > 0,
+// same n), whose blocks add them up themselves.  Returns the number of partials (>= 1) or a negative status.
+extern "C" int sx_grad_sumsq_partial(const float* g, int64_t n, void* stream) {
+  SX_REQUIRE(g && n > 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq_partial: bad arguments");
+  const int blocks = sumsq_blocks(n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n);
+  SX_LAUNCH_CHECK("grad_sumsq");
+  return blocks;
+}
+
 extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
   SX_REQUIRE(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq: bad arguments");
   if (n == 0) return SX_OK;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 256));
+  const int blocks = sumsq_blocks(n);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n);
   SX_LAUNCH_CHECK("grad_sumsq");
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, blocks, out);
@@ -109,6 +134,8 @@ extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.max_norm = max_norm; a.gnorm_sq = gnorm_sq; a.grad_mul = grad_mul; a.gnorm_out = gnorm_out; a.clear_after = clear_after;
+  // gnorm_sq == NULL with clipping on: the partials of sx_grad_sumsq_partial(g, n) (same stream, same device, just before)
+  a.fused_parts = (!gnorm_sq && max_norm > 0.f) ? sumsq_blocks(n) : 0;
   SX_REQUIRE(!clear_after || clear_after != gnorm_sq, "sx_adamw_step: clear_after must not alias gnorm_sq");
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 2048));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

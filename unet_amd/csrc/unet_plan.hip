@@ -203,11 +203,6 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
 static inline char* at(void* base, int64_t off) { return (char*)base + off; }
 static inline const char* at(const void* base, int64_t off) { return (const char*)base + off; }
 
-__global__ void pad_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n, int npad) {
-  const int i = threadIdx.x;
-  if (i < npad) out[i] = i < n ? b[i] : 0.f;
-}
-
 // ---------------------------------------------------------------- FiLM helpers
 static void film_fill(const Plan& p, int k, const float* const* params, float* const* grads, void* ws, FilmGenDesc& g) {
   const BlockBuf& b = p.blk[k];
@@ -496,11 +491,10 @@ extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* p
   }
   SX_TRY(add(SX_CONV1, 0, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headf)));
   SX_TRY(add(SX_CONV1, 1, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headd)));
-  SX_TRY(pack_weights_multi(dt, pk.data(), (int)pk.size(), (hipStream_t)stream));
   SX_REQUIRE(p.out_pad <= 64, "sx_unet_pack_weights: out_ch %d too large", d->out_ch);
-  hipLaunchKernelGGL(pad_bias_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, params[p.out_pidx + 1], (float*)at(wpack, p.head_bias), d->out_ch, p.out_pad);
-  SX_LAUNCH_CHECK("pad_bias");
-  return SX_OK;
+  PackPad pad;                                     // the head's bias, zero padded, rides on the packing launch
+  pad.src = params[p.out_pidx + 1]; pad.dst = (float*)at(wpack, p.head_bias); pad.n = d->out_ch; pad.npad = p.out_pad;
+  return pack_weights_multi(dt, pk.data(), (int)pk.size(), (hipStream_t)stream, &pad);
 }
 
 extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,

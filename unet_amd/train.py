@@ -123,7 +123,6 @@ class TrainEngine:
             from .data import norm_table
             self._ev_table = norm_table(norm, self.cfg["out_ch"])
         self._sessions = {}
-        self._ss = torch.zeros(2, dtype=torch.float32, device=self.device)   # ping-pong: the AdamW kernel clears the other slot
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.accum = 0
         # device-side per-batch log rows [loss, sum|p-t|*m, px (global under DP), px (local)], read once per epoch
@@ -257,14 +256,13 @@ class TrainEngine:
         self.step_count += 1
         n = self.n_kernel if n is None else int(n)
         use_clip = bool(self.clip and self.clip > 0)
-        cur, nxt = self._ss[self.step_count & 1:], self._ss[(self.step_count + 1) & 1:]
         if use_clip:
-            L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(cur), L.stream_ptr()), "sx_grad_sumsq")
+            # deterministic block partials of sum g^2; the AdamW blocks add them up themselves (no one-block launch between)
+            L.check(lib.sx_grad_sumsq_partial(L.ptr(self.flat_g), n, L.stream_ptr()), "sx_grad_sumsq_partial")
         L.check(lib.sx_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n,
                                   float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
-                                  self.step_count, float(self.clip) if use_clip else 0.0, L.ptr(cur) if use_clip else None,
-                                  1.0, L.ptr(self.gnorm) if use_clip else None, L.ptr(nxt) if use_clip else None,
-                                  L.stream_ptr()), "sx_adamw_step")
+                                  self.step_count, float(self.clip) if use_clip else 0.0, None,
+                                  1.0, L.ptr(self.gnorm) if use_clip else None, None, L.stream_ptr()), "sx_adamw_step")
         self.accum = 0
         self.model._wgen += 1          # the kernel wrote the parameters through raw pointers: packed-weight caches are stale
 
@@ -335,7 +333,6 @@ class TrainEngine:
             self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(float(st["step"]))
-            self._ss.zero_()          # both sum-of-squares slots clean whatever the new step parity is
 
 
 def train_unet(
