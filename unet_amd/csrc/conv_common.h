@@ -67,9 +67,11 @@ template <> struct Mma<float> {
 
 
 // weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
+// WS_GATHER: the data gradient of ConvTranspose2d(2,2) as a 1x1 convolution over K = 4 taps x Cin gathered from the
+// fine grid (output pixel (y, x), tap (ty, tx) reads input pixel (2y + ty, 2x + tx)).
 // var: 0 plain; WS_DUAL: y2 = conv1x1(x, w2) beside the 3x3 (same input tile); WS_CENTER: the input has 2K channels and
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
-enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3 };
+enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3, WS_GATHER = 4 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
 
 // Weight packing for a whole table of layers in one launch (conv_igemm.hip).

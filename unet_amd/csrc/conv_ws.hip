@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   constexpr int DIST = NBUF - 1;                // stages in flight
   constexpr int KTOT = VAR == WS_CENTER ? 2 * KCH : KCH;   // K chunks (= pipeline stages) per tile
   constexpr int CT = TAPS / 2;                  // centre tap
-  static_assert(VAR == WS_PLAIN || VAR == WS_BS || TAPS == 9, "fused variants are 3x3 only");
+  static_assert(VAR == WS_PLAIN || VAR == WS_BS || VAR == WS_GATHER || TAPS == 9, "fused variants are 3x3 only");
+  static_assert(VAR != WS_GATHER || (TAPS == 1 && KCH % 4 == 0), "the gather variant is a 1x1 over 4 taps x K chunks");
+  constexpr bool GA = VAR == WS_GATHER;
   constexpr bool BS = VAR == WS_BS;
   // (block-output sums -- four per channel, FiLM / dropout factors, for the 1x1 head's data gradient -- were built and
   // measured: 45 us fused against 17 + 26 us for the two launches.  A 1x1 launch is all epilogue, and at one wave per SIMD
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       }
   }
   // 1x1 weights of the fused variants: A2[kc][j] = W2[cb + (wm*MI+j)*16 + n][kc*32 + 8g .. +8]
-  bf16x8 A2[(VAR == WS_PLAIN || BS) ? 1 : KCH][MI];
+  bf16x8 A2[(VAR == WS_PLAIN || BS || GA) ? 1 : KCH][MI];
   if constexpr (VAR == WS_DUAL || VAR == WS_CENTER) {
     const bf16* __restrict__ wg2 = reinterpret_cast<const bf16*>(a.w2);
 #pragma unroll
@@ -141,8 +143,13 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     const int p = tid + q * 256;
     const int r = p >> 2;
     const int ly = r / LW, lx = r - ly * LW;
-    st_lx[q] = p < PIECES ? lx - PAD : -100000;
-    st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + (p & 3) * 16;
+    if constexpr (GA) {        // stage kk = 4*kc + tap of output pixel (ly, lx): input pixel (2*ly + tap/2, 2*lx + tap%2)
+      st_lx[q] = p < PIECES ? 2 * lx : -100000;
+      st_rel[q] = 2 * ly * row_bytes + 2 * lx * a.x_ld * 2 + (p & 3) * 16;
+    } else {
+      st_lx[q] = p < PIECES ? lx - PAD : -100000;
+      st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + (p & 3) * 16;
+    }
   }
   const int nr = n >> TWL, nc = n & (TW - 1);      // this lane's pixel inside a fragment
   const int frag_off = ((wn * NI * RPF + nr) * LW + nc) * 64 + g * 16;
@@ -155,8 +162,9 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     const bool live = is < nst;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(xg + (int64_t)ip.b * a.Hx * a.Wx * a.x_ld), 0, live ? img_bytes : 0, 0x00020000);
-    const int x0 = ip.tx * TW;
-    const int tile_off = ip.ty * TH * row_bytes + x0 * a.x_ld * 2 + ikc * 64;
+    const int x0 = GA ? 2 * ip.tx * TW + (ikc & 1) : ip.tx * TW;
+    const int tile_off = GA ? (2 * ip.ty * TH + ((ikc >> 1) & 1)) * row_bytes + x0 * a.x_ld * 2 + (ikc >> 2) * 64
+                            : ip.ty * TH * row_bytes + x0 * a.x_ld * 2 + ikc * 64;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const unsigned ix = (unsigned)(x0 + st_lx[q]);
@@ -569,6 +577,18 @@ int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
     if (var != WS_PLAIN || a.W < 8 || a.R % 4 || a.accumulate || a.gn_stats || a.KPad % 32 || a.KPad > 256) return 1;
     if (a.bias && ((uintptr_t)a.bias % 16)) return 1;
     return ws_pick_k<1, WS_PLAIN>(a, st);
+  }
+  if (mode == SX_CONVT_BWD) {
+    // 1x1 over the 4 taps x K/32 chunks of the packed [row block][chunk][tap] layout (K = 128 -> 16 stationary units)
+    if (var != WS_PLAIN || a.W < 8 || a.R % 4 || a.accumulate || a.gn_stats || a.ch_sum || a.bias || a.KPad % 32 || a.K != a.KPad) return 1;
+    ConvArgs h = a;
+    h.KRow = 4 * a.KPad;
+    switch (a.KPad / 32) {
+      case 1: return ws_pick_tile<4, 1, WS_GATHER>(h, st);
+      case 2: return ws_pick_tile<8, 1, WS_GATHER>(h, st);
+      case 4: return ws_pick_tile<16, 1, WS_GATHER>(h, st);
+    }
+    return 1;
   }
   if (mode != SX_CONV3 && mode != SX_CONV1) return 1;
   if (a.W < 8 || a.bias || a.shuffle || a.R % 4) return 1;
