@@ -60,8 +60,8 @@ def conv_launches(B):
     training step of cfg A: (kind, H, W, Cin, Cout, algorithmic flops).
     kind: "dual" = conv1 3x3 + 1x1 shortcut forward (one launch), "c3"/"c1" = plain 3x3 / 1x1 (forward or data gradient),
     "center" = joint data gradient of conv1 + shortcut, "ct" = ConvTranspose2d(2,2) forward (four 1x1 GEMMs + pixel
-    shuffle, H x W = its INPUT grid).  Flops count the REAL channels (the 1-channel input is padded to 8).  The
-    transposed convolutions' data gradients run in conv_igemm_kernel and the weight gradients in wgrad_ws_kernel."""
+    shuffle, H x W = its INPUT grid), "ctb" = its data gradient (a 1x1 over 4 taps x Cin gathered from the fine grid).
+    Flops count the REAL channels (the 1-channel input is padded to 8).  The weight gradients run in wgrad_ws_kernel."""
     C = [32, 64, 128, 256]
     Hs = [(128, 64), (64, 32), (32, 16), (16, 8)]
     out = []
@@ -81,6 +81,7 @@ def conv_launches(B):
         h, w = Hs[l + 1]
         out.append(("ct", h, w, C[l + 1], C[l], 2.0 * B * h * w * C[l + 1] * C[l] * 4))
         block(Hs[l], 2 * C[l], 2 * C[l], C[l], True)
+        out.append(("ctb", h, w, C[l], C[l + 1], 2.0 * B * h * w * C[l + 1] * C[l] * 4))   # its data gradient (H x W = its OUTPUT grid)
     h, w = Hs[0]
     out.append(("c1", h, w, 8, 32, 2.0 * B * h * w * 32 * 8))             # head data gradient (the head's forward has a bias:
     return out                                                            # conv_igemm_kernel)
@@ -127,6 +128,13 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
                 L.check(lib.sx_conv_forward(sx_dtype, 2, B, h, w, cin, cout, L.ptr(x), cin, h, w, L.ptr(wp), L.ptr(bias), L.ptr(y),
                                             2 * cout, 2 * h, 2 * w, 0, None, 0, L.stream_ptr()))
             return launch, (x, y[..., :cout], wp)
+        if kind == "ctb":
+            x, y = rnd(B, 2 * h, 2 * w, 2 * cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt)   # reads the lower half of d(cat)
+            wp = packed(3, cout, cin)
+            def launch():
+                L.check(lib.sx_conv_forward(sx_dtype, 3, B, h, w, cin, cout, L.ptr(x), 2 * cin, 2 * h, 2 * w, L.ptr(wp), None, L.ptr(y),
+                                            cout, h, w, 0, None, 0, L.stream_ptr()))
+            return launch, (x[..., :cin], y, wp)
         if kind == "c3bs":
             x, y, y1 = rnd(B, h, w, cin), torch.empty(B, h, w, cout, device="cuda", dtype=tdt), rnd(B, h, w, cout)
             wp = packed(0, cout, cin)
