@@ -67,8 +67,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int nw_pieces = a.ntaps * BMC * 4;
   const int iy0 = ty0 * a.in_scale - a.pad, ix0 = tx0 * a.in_scale - a.pad;
 
+  // fp32: the next K chunk's pieces are fetched into registers under this chunk's MFMAs (8 + 9 pieces per thread at most:
+  // the transposed conv's 512-pixel gather image, nine taps x 64 rows of weights); coordinates are decoded once
+  constexpr bool PREFETCH = sizeof(T) == 4;
+  constexpr int NPX = PREFETCH ? 8 : 1, NPW = PREFETCH ? 9 : 1;
+  Vec pre_x[NPX], pre_w[NPW];
+  int64_t px_off[NPX], pw_off[NPW];      // element offsets without the chunk term; < 0 = piece reads as zero
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = tid + i * 256, r = p >> 2, q = p & 3;
+      const int ly = r / a.LW, lx = r - ly * a.LW;
+      const int iy = iy0 + ly, ix = ix0 + lx;
+      const bool ok = p < npix_pieces && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+      px_off[i] = ok ? ((int64_t)(b * a.Hx + iy) * a.Wx + ix) * a.x_ld + q * EPL : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int p = tid + i * 256, r = p >> 2, q = p & 3;
+      const int tap = r / BMC, row = r - tap * BMC;
+      const bool ok = p < nw_pieces && cb + row < a.RTot;
+      pw_off[i] = ok ? ((int64_t)tap * a.RTot + cb + row) * a.KPad + q * EPL : -1;
+    }
+  }
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      Vec v = {};
+      if (px_off[i] >= 0 && kc + ((tid + i * 256) & 3) * EPL < a.K) v = *reinterpret_cast<const Vec*>(xg + px_off[i] + kc);
+      pre_x[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      Vec v = {};
+      if (pw_off[i] >= 0) v = *reinterpret_cast<const Vec*>(wg + pw_off[i] + kc);
+      pre_w[i] = v;
+    }
+  };
+  if constexpr (PREFETCH) fetch(0);
   for (int kc = 0; kc < a.KPad; kc += CK) {
     __syncthreads();
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int p = tid + i * 256;
+        if (p < npix_pieces) *reinterpret_cast<Vec*>(sm_pix + (p >> 2) * ROWB + (p & 3) * 16) = pre_x[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        const int p = tid + i * 256;
+        if (p < nw_pieces) *reinterpret_cast<Vec*>(sm_w + (p >> 2) * ROWB + (p & 3) * 16) = pre_w[i];
+      }
+      __syncthreads();
+      if (kc + CK < a.KPad) fetch(kc + CK);
+    } else {
     for (int p = tid; p < npix_pieces; p += 256) {
       const int r = p >> 2, q = p & 3;
       const int ly = r / a.LW, lx = r - ly * a.LW;
@@ -90,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       *reinterpret_cast<Vec*>(sm_w + r * ROWB + q * 16) = v;
     }
     __syncthreads();
+    }
     for (int tap = 0; tap < a.ntaps; ++tap) {
       const int tyy = tap / a.tapw, txx = tap - tyy * a.tapw;
       const int toff = (tyy * a.LW + txx) * ROWB;
@@ -177,6 +230,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   size_t stat_bytes = (size_t)WN * BMC * 2 * sizeof(float);
   if (smem < stat_bytes) smem = stat_bytes;
   if (smem > 160 * 1024) { set_error("conv tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
+  if (sizeof(T) == 4 && (a.LH * a.LW * 4 > 8 * 256 || a.ntaps * BMC * 4 > 9 * 256)) {      // the kernel's register-prefetch slots
+    set_error("conv: fp32 tile of %d pixels x %d taps exceeds the prefetch slots", a.LH * a.LW, a.ntaps);
+    return SX_ERR_UNSUPPORTED;
+  }
   auto kern = conv_igemm_kernel<T, MI, NI, WM, WN>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv)"));
