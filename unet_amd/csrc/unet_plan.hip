@@ -283,6 +283,12 @@ struct WgQueue {
       SX_TRY(wgrad_ws_launch(launches.data(), (int)launches.size(), st));
       launches.clear();
     }
+    static const int report = env_int("SX_WG_REPORT", 0);        // diagnostic: slab bytes of this half (tools/wgrad_slabs.sh)
+    if (report) {
+      double bytes = 0;
+      for (const WgReduceDesc& d : pending) bytes += (double)d.nsplit * (d.a16_n ? d.tap_n * d.a16_n * 16 : d.ntaps * d.CaPad) * d.CbPad * 4;
+      fprintf(stderr, "[sx] weight-gradient slabs of this half: %zu problems, %.1f MB written + read\n", pending.size(), bytes / 1e6);
+    }
     if (!pending.empty()) SX_TRY(wgrad_reduce_multi(pending.data(), (int)pending.size(), st));
     pending.clear();
     used = 0;
