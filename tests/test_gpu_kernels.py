@@ -101,7 +101,8 @@ def test_conv3x3_forward_stats_and_dgrad(L, dtype, B, H, W, Cin, Cout):
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 8, 32), (2, 24, 16, 32, 64), (1, 16, 32, 64, 128), (3, 16, 8, 128, 256),
                                              (1, 32, 16, 256, 128), (2, 16, 16, 128, 64), (2, 40, 16, 64, 32), (2, 16, 8, 256, 128),
-                                             (2, 13, 7, 16, 24), (1, 20, 12, 128, 128)])
+                                             (2, 13, 7, 16, 24), (1, 20, 12, 128, 128), (2, 16, 8, 16, 8), (2, 16, 8, 8, 8),
+                                             (2, 8, 8, 32, 16), (2, 16, 8, 1 * 8, 16)])
 def test_conv3_shortcut_fused_forward_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     """DoubleConv fusions: conv1 + 1x1 shortcut from one pass over the input, and their joint data gradient from the
     [dY1 | dR] buffer; shapes cover every tile configuration of the fused kernel variants and the unfused fallbacks."""
@@ -143,6 +144,37 @@ def test_conv3_shortcut_fused_forward_and_dgrad(L, dtype, B, H, W, Cin, Cout):
     got = from_nhwc(dx, Cin)
     assert rel_err(chs.cpu(), got[:, :nsum].sum(dim=(0, 2, 3))) < (1e-4 if dtype == 0 else 3e-3)
     assert float((dx[..., Cin:].float() - 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,off", [(2, 16, 8, 8, 16, 0), (2, 16, 8, 8, 16, 8), (1, 16, 16, 16, 32, 0), (2, 8, 8, 24, 8, 0),
+                                                 (2, 16, 16, 40, 32, 0), (3, 16, 8, 8, 8, 8)])
+def test_conv_channel_padding_does_not_read_what_follows_the_tensor(L, mode, B, H, W, Cin, Cout, off):
+    """K is walked in chunks of 32 channels; with Cin % 32 != 0 the tail of a chunk lies in the next pixels -- or, at the
+    last pixels of the last image, in whatever follows the tensor in memory.  That must never enter the sums (here: NaN
+    right behind the tensor; `off` = the input is the upper channel half of a wider [A | B] buffer, as the joint data
+    gradient's fallback reads it).  bf16 tier (the weights-stationary kernel); the generic kernel guards per element."""
+    dtype = 1
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + mode)
+    k = 3 if mode == 0 else 1
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5), dtype)
+    ld = Cin + off
+    n = B * H * W * ld
+    big = torch.full((n + 256,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    buf = big[:n].view(B, H, W, ld)
+    buf[...] = 1.0
+    buf[..., off:] = x.permute(0, 2, 3, 1).to(torch.bfloat16).cuda()
+    xin = buf[..., off:]
+    wp = pack(L, dtype, mode, 0, w, Cout, Cin, Cout, Cin)
+    y = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().sx_conv_forward(dtype, mode, B, H, W, Cin, Cout, xin.data_ptr(), ld, H, W, L.ptr(wp), None, L.ptr(y), Cout, H, W,
+                                    0, None, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, padding=k // 2)
+    got = from_nhwc(y, Cout)
+    assert bool(torch.isfinite(got).all()), torch.isnan(got).nonzero()[:4].tolist()
+    assert rel_err(got, ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("Cin,Cout", [(32, 64), (128, 32), (256, 128), (64, 256)])

@@ -98,6 +98,41 @@ def test_train_unet_two_epochs_match_reference_history(golden, tmp_path):
     np.testing.assert_allclose(outs[0], out, rtol=1e-4, atol=1e-4 * np.abs(out).max())
 
 
+def test_train_unet_bf16_loop_tracks_the_reference_history(golden, tmp_path):
+    """amp=True (the bf16 tier) through the same two epochs: the reference's fp32 history is the yardstick, at bf16
+    tolerance (activations carry 8 mantissa bits: 1e-2 on the losses, 3e-2 on the physical-unit errors, which pass through
+    exp() of the Log / SymLog normalisers).  The learning-rate schedule is exact."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.models import UNet
+    from unet_amd.train import train_unet
+    from unet_amd.synth import make_batch, CHANNEL_WEIGHTS_8
+    g = golden("train_history.npz")
+    cfg = UNetCfg(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2)
+    sd = init_state_dict(cfg, seed=4)
+    tr = make_batch(6, 16, 8, seed=100, jitter_masks=True)
+    va = make_batch(4, 16, 8, seed=101, jitter_masks=True)
+    tl = torch.utils.data.DataLoader(_ListDS(tr), batch_size=2, shuffle=False)
+    vl = torch.utils.data.DataLoader(_ListDS(va), batch_size=2, shuffle=False)
+
+    def mk(in_ch, out_ch):
+        m = UNet(in_ch=in_ch, out_ch=out_ch, base=8, P=5, film_hidden=16, depth=2)
+        m.load_state_dict(sd)
+        return m
+    model, hist = train_unet(tl, vl, _norm(), 1, "cuda", out_ch=8, lam_grad=0.1, lam_w=0.5, epochs=2, base=8, model_cls=mk,
+                             P=5, film_hidden=16, depth=2, save_path=str(tmp_path / "b.pt"), multiscale=1, lr_init=2e-3,
+                             amp=True, lam_grad_warmup_start=0, lam_grad_warmup_end=1, channel_weights=CHANNEL_WEIGHTS_8,
+                             param_scaler=(np.zeros(5, np.float32), np.ones(5, np.float32)))
+    worst = {}
+    for k, tol in (("tr_mse", 1e-2), ("tr_maeN", 1e-2), ("va_mse", 1e-2), ("va_maeN", 1e-2), ("va_mae_eV", 3e-2), ("va_rmse_eV", 3e-2)):
+        got, ref = np.asarray(hist[k], np.float64), np.asarray(g["hist_" + k], np.float64)
+        worst[k] = float(np.max(np.abs(got - ref) / np.abs(ref)))
+        assert worst[k] < tol, (k, worst)
+    np.testing.assert_allclose(np.asarray(hist["lr"]), g["hist_lr"], rtol=1e-6)
+    fin = model.state_dict()
+    for k in ("out.weight", "encoders.0.net.0.weight"):
+        assert rel_err(fin[k].cpu(), g["final::" + k]) < 3e-2, k
+
+
 def test_engine_step_equals_autograd_path_and_oracle_adamw():
     """TrainEngine.train_step (direct C calls, flat arenas) == autograd path + oracle AdamW/clip on the same batch."""
     from oracle import optim_ref

@@ -135,8 +135,11 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   // Per image one buffer resource (num_records = image bytes): rows above / below the image fall outside it and
   // the hardware returns zeros; columns left / right of the image are forced out of range by hand.
   // (K chunks beyond the real channel count read neighbouring finite data; their packed weights are zero.)
+  // (The resource ends with the last pixel's K channels, not with its row of x_ld channels: when the input is a channel slice
+  // of a wider buffer, the bytes behind that point belong to the next image or to whatever follows the tensor in memory --
+  // fp32 scratch read as bf16 has NaN patterns, and 0 x NaN poisoned the last pixels of the last image.)
   const int row_bytes = a.Wx * a.x_ld * 2;
-  const int img_bytes = a.Hx * row_bytes;
+  const int img_bytes = a.Hx * row_bytes - (a.x_ld - (VAR == WS_CENTER ? 2 : 1) * a.K) * 2;
   int st_rel[NP], st_lx[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
