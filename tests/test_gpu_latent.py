@@ -139,3 +139,51 @@ def test_extract_z_dataset_matches_module_calls(tmp_path):
     assert np.allclose(Z[5], z5, rtol=1e-4, atol=1e-5)
     Z2, _, _ = extract_z_dataset(ae_model=model, dataset=ds, device="cuda", batch_size=4, max_batches=2)
     assert Z2.shape[0] == 8
+
+
+def test_eval_param2z_one_and_sample_from_resident_loader(tmp_path):
+    """The latent pipeline's evaluation helpers (solpex/utils.py:11-15,50-97; scripts/run_latent_pipeline.py:323-350) on the
+    HIP path: a sample picked from a device-resident loader, the autoencoder's latent against the params -> z MLP's."""
+    from oracle import unet_ref
+    from oracle.unet_ref import UNetCfg
+    from unet_amd import data as D
+    from unet_amd.models import UNet
+    from unet_amd.latent import ParamToZ
+    from unet_amd.utils import sample_from_loader, eval_param2z_one, nearest_neighbor_in_Z, pick_device
+    rng = np.random.default_rng(3)
+    N, H, W = 12, 16, 8
+    path = str(tmp_path / "d.npz")
+    np.savez(path, Te=np.abs(rng.normal(size=(N, H, W))).astype(np.float32), mask=np.ones((H, W), np.float32),
+             X=rng.normal(size=(N, 5)).astype(np.float32))
+    dev = pick_device()
+    assert dev.type == "cuda"
+    tl, vl, norm, P, hw, (mu, std), pt, pk = D.make_loaders(path, batch_size=4, device=dev, resident=True)
+    assert isinstance(tl, D.ResidentLoader)
+    gidx, s = sample_from_loader(tl, k=2)
+    assert gidx == tl.dataset.indices[2] and int(s["idx"]) == gidx and s["x"].shape == (1, H, W)
+    torch.manual_seed(0)
+    ae = UNet(in_ch=1, out_ch=1, base=8, P=5, film_hidden=16, depth=2).to(dev)
+    mlp = ParamToZ(5, 32, hidden=(16, 16)).to(dev)
+    z_mu, z_std = np.linspace(-0.1, 0.1, 32).astype(np.float32), np.linspace(0.5, 1.5, 32).astype(np.float32)
+    out = eval_param2z_one(ae=ae, mlp=mlp, sample=s, device=dev, label="", z_mu=z_mu, z_std=z_std, p_mu=mu, p_std=std)
+    assert set(out) == {"z_true", "z_pred", "cos", "z_true_norm", "z_pred_norm"}
+    assert out["z_true"].shape == (1, 32) and out["z_pred"].shape == (1, 32) and not out["z_true"].is_cuda
+    # oracle: the same two evaluations in plain PyTorch on the CPU
+    cfg = UNetCfg(in_ch=1, out_ch=1, base=8, P=5, film_hidden=16, depth=2)
+    sd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    _, b = unet_ref.unet_forward(sd, cfg, s["x"][None], s["params"][None], return_bottleneck=True)
+    z_true = b.mean(dim=(2, 3))
+    msd = {k: v.detach().cpu() for k, v in mlp.state_dict().items()}
+    p = (s["params"].numpy() - mu) / std
+    h = torch.from_numpy(p.astype(np.float32))[None]
+    lin = [k[:-len(".weight")] for k in msd if k.endswith(".weight")]
+    for i, name in enumerate(lin):
+        h = h @ msd[name + ".weight"].T + msd[name + ".bias"]
+        if i + 1 < len(lin):
+            h = torch.nn.functional.silu(h)
+    z_pred = h * torch.from_numpy(z_std)[None] + torch.from_numpy(z_mu)[None]
+    assert rel_err(out["z_true"], z_true) < 1e-4 and rel_err(out["z_pred"], z_pred) < 1e-4
+    cos = float(torch.nn.functional.cosine_similarity(z_true, z_pred).item())
+    assert abs(out["cos"] - cos) < 1e-4
+    j, d2 = nearest_neighbor_in_Z(out["z_pred"][0].numpy(), np.stack([z_true[0].numpy(), out["z_pred"][0].numpy()]))
+    assert j == 1 and d2 == 0.0

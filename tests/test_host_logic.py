@@ -128,3 +128,35 @@ def test_resident_loader_batch_order_mirrors_the_host_loader(tmp_path):
     assert host == mirror
     with pytest.raises(RuntimeError):
         D.ResidentLoader(tl.dataset, 4, True, "cpu")
+
+
+def test_utils_helpers_have_the_reference_return_values(tmp_path):
+    """solpex/utils.py:11-48 as the pipeline scripts call them: `idx, sample = sample_from_loader(loader, k)`,
+    `pick_device()` -> torch.device, parameter scaling, nearest latent."""
+    import torch
+    from unet_amd import data as D
+    from unet_amd import utils as U
+    import unet_amd
+    import solpex
+    rng = np.random.default_rng(2)
+    N, H, W = 12, 8, 8
+    path = str(tmp_path / "d.npz")
+    np.savez(path, Te=np.abs(rng.normal(size=(N, H, W))).astype(np.float32), mask=np.ones((H, W), np.float32),
+             X=rng.normal(size=(N, 5)).astype(np.float32))
+    tl, vl, *_ = D.make_loaders(path, batch_size=4, device="cpu")
+    for loader in (tl, vl):
+        gidx, s = U.sample_from_loader(loader, k=1)
+        assert gidx == loader.dataset.indices[1]
+        ref = loader.dataset.dataset[gidx]
+        assert set(s.keys()) == set(ref.keys()) and int(s["idx"]) == gidx
+        assert torch.equal(s["x"], ref["x"]) and torch.equal(s["y"], ref["y"])
+    dev = U.pick_device()
+    assert isinstance(dev, torch.device) and dev.type in ("cuda", "mps", "cpu")
+    p = U.scale_params_for_inference([1.0, 2.0, 3.0], [1.0, 1.0, 1.0], [2.0, 2.0, 2.0])
+    assert p.dtype == np.float32 and np.allclose(p, [0.0, 0.5, 1.0])
+    assert np.allclose(U.scale_params_for_inference([1, 2], None, None), [1.0, 2.0])
+    Z = np.array([[0.0, 0.0], [1.0, 1.0], [3.0, 0.0]])
+    j, d2 = U.nearest_neighbor_in_Z(np.array([0.9, 1.2]), Z)
+    assert j == 1 and abs(d2 - 0.05) < 1e-12
+    for name in ("pick_device", "sample_from_loader", "eval_param2z_one", "nearest_neighbor_in_Z"):   # solpex/__init__.py:11
+        assert getattr(solpex, name) is getattr(unet_amd, name)

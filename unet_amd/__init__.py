@@ -10,7 +10,8 @@ from .models import UNet, ParamToZ, bottleneck_to_z, z_to_bottleneck
 from .losses import edge_weights, masked_weighted_loss, mae_norm, batch_error_sums_ev
 from .train import train_unet, TrainEngine
 from .predict import load_checkpoint, predict_fields, predict_te, predict_fields_batch, scale_params
-from .utils import pick_device, sample_from_loader
+from .utils import (pick_device, sample_from_loader, eval_param2z_one, nearest_neighbor_in_Z, scale_params_for_inference,
+                    save_geometry_h5)
 from .latent import (extract_z_dataset, ParamToZ, ZToParam, train_param2z, train_z2param,   # noqa: F811  (as the reference,
                      train_cycle_consistent)                                              # latent.ParamToZ wins)
 from .data import ResidentLoader
@@ -20,6 +21,7 @@ __all__ = [
     "SOLPSDataset", "make_loaders", "normalize_coords", "load_geometry_h5", "apply_param_transform",
     "invert_param_transform", "UNet", "ParamToZ", "bottleneck_to_z", "z_to_bottleneck", "edge_weights",
     "masked_weighted_loss", "mae_norm", "batch_error_sums_ev", "train_unet", "TrainEngine", "load_checkpoint",
-    "predict_fields", "predict_te", "predict_fields_batch", "scale_params", "pick_device", "sample_from_loader", "extract_z_dataset", "ZToParam", "train_param2z", "train_z2param",
+    "predict_fields", "predict_te", "predict_fields_batch", "scale_params", "pick_device", "sample_from_loader", "eval_param2z_one",
+    "nearest_neighbor_in_Z", "scale_params_for_inference", "save_geometry_h5", "extract_z_dataset", "ZToParam", "train_param2z", "train_z2param",
     "train_cycle_consistent", "ResidentLoader",
 ]
