@@ -326,3 +326,57 @@ def test_cfg5_shape_against_oracle():
     loss.backward()
     assert float(loss) == 0.0
     assert all(float(q.grad.abs().max()) == 0.0 for q in model.parameters())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,Cin,Cc,H,W", [(2, 1, 8, 16, 8), (2, 16, 32, 16, 16), (1, 32, 32, 8, 8), (2, 24, 16, 12, 10)])
+def test_sub_blocks_called_on_their_own_match_the_oracle(dtype, tol, B, Cin, Cc, H, W):
+    """The reference lets callers run `DoubleConv`, `FiLMGenerator` and `UNet._apply_film` directly (solpex/models.py:52-58,
+    79-80, 152-156).  Here they take the HIP kernels one C-ABI call at a time: output, input gradient and every parameter
+    gradient against the oracle (fp32 <= 1e-4; bf16 tier at bf16 tolerance).  Cin == Cc exercises the Identity shortcut."""
+    from oracle import unet_ref
+    from unet_amd.models import DoubleConv, FiLMGenerator, UNet
+    from helpers import rel_err
+    torch.manual_seed(B * 100 + Cin + Cc)
+    blk = DoubleConv(Cin, Cc).cuda()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(B, Cin, H, W)
+    dy = torch.randn(B, Cc, H, W)
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = unet_ref.double_conv(sd, "b", xr, 8)
+    ref.backward(dy)
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    out = blk(xd)
+    assert out.shape == (B, Cc, H, W) and out.dtype == dtype
+    out.backward(dy.cuda().to(dtype))
+    assert rel_err(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < tol * (1 if dtype == torch.float32 else 2)
+    for k, p in blk.named_parameters():
+        assert p.grad is not None and rel_err(p.grad.float().cpu(), sd["b." + k].grad) < tol * (1 if dtype == torch.float32 else 3), k
+    assert isinstance(blk.shortcut, torch.nn.Identity) == (Cin == Cc)
+    # FiLM generator + _apply_film (fp32 MLP whatever the feature dtype)
+    gen = FiLMGenerator(5, Cc, hidden=16).cuda()
+    with torch.no_grad():
+        gen.net[2].weight.normal_(0.0, 0.3)
+        gen.net[2].bias.normal_(0.0, 0.1)
+    prm = torch.randn(B, 5)
+    gsd = {"f." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in gen.state_dict().items()}
+    pr = prm.clone().requires_grad_(True)
+    g_ref, b_ref = unet_ref.film_generator(gsd, "f", pr, Cc)
+    feat = out.detach()
+    mod_ref = feat.float().cpu() * g_ref + b_ref
+    mod_ref.sum().backward()
+    pd = prm.cuda().requires_grad_(True)
+    g, b = gen(pd)
+    assert g.shape == (B, Cc, 1, 1) and b.shape == (B, Cc, 1, 1)
+    assert rel_err(g.detach().cpu(), g_ref.detach()) < 1e-4 and rel_err(b.detach().cpu(), b_ref.detach()) < 1e-4
+    mod = UNet._apply_film(feat, gen, pd)
+    assert mod.dtype == dtype and rel_err(mod.detach().float().cpu(), mod_ref.detach()) < tol
+    mod.float().sum().backward()
+    assert rel_err(pd.grad.cpu(), pr.grad) < tol
+    for k, p in gen.named_parameters():
+        assert rel_err(p.grad.cpu(), gsd["f." + k].grad) < tol, k

@@ -84,12 +84,9 @@ class ParamToZ(nn.Module):
         return self.net(p)
 
 
-_SUBMODULE_MSG = ("{} is a parameter container in the MI355X build; its arithmetic runs fused inside "
-                  "UNet.encode/decode (HIP kernels).  Call the UNet instead.")
-
-
 class FiLMGenerator(nn.Module):
-    """Parameters of one FiLM generator (solpex/models.py:38-58); evaluated by the film kernels."""
+    """One FiLM generator (solpex/models.py:38-58).  Inside UNet.encode/decode all generators of a network half are
+    evaluated by one launch of the film kernels; a direct call runs the same two-layer MLP on its own (blocks.py)."""
 
     def __init__(self, P: int, n_channels: int, hidden: int = 128):
         super().__init__()
@@ -99,11 +96,14 @@ class FiLMGenerator(nn.Module):
         self.n_channels = n_channels
 
     def forward(self, params):
-        raise NotImplementedError(_SUBMODULE_MSG.format("FiLMGenerator"))
+        """params (B, P) -> (1 + gamma, beta), each (B, C, 1, 1)"""
+        from .blocks import film_forward
+        return film_forward(self, params)
 
 
 class DoubleConv(nn.Module):
-    """Parameters of conv3-GN-SiLU-conv3-GN-SiLU + 1x1 shortcut (solpex/models.py:61-80)."""
+    """conv3-GN-SiLU-conv3-GN-SiLU + 1x1 shortcut (solpex/models.py:61-80).  Inside UNet.encode/decode the block runs fused
+    in the network plan; a direct call `block(x)` takes the same kernels one C-ABI call at a time (blocks.py)."""
 
     def __init__(self, in_ch, out_ch, groups_gn=8):
         super().__init__()
@@ -114,7 +114,8 @@ class DoubleConv(nn.Module):
         self.shortcut = nn.Conv2d(in_ch, out_ch, 1, bias=False) if in_ch != out_ch else nn.Identity()
 
     def forward(self, x):
-        raise NotImplementedError(_SUBMODULE_MSG.format("DoubleConv"))
+        from .blocks import double_conv_forward
+        return double_conv_forward(self, x)
 
 
 def _put(dst, src):
@@ -324,7 +325,9 @@ class UNet(nn.Module):
     # ------------------------------------------------------------------ public API (reference: models.py:152-213)
     @staticmethod
     def _apply_film(features, film_layer, params):
-        raise NotImplementedError(_SUBMODULE_MSG.format("UNet._apply_film"))
+        """features * gamma + beta (solpex/models.py:152-156); the fused path applies it inside the block-output kernel."""
+        from .blocks import apply_film
+        return apply_film(features, film_layer, params)
 
     def project_z(self, b):
         z = bottleneck_to_z(b)
