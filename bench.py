@@ -87,16 +87,13 @@ def conv_launches(B):
     return out                                                            # conv_igemm_kernel)
 
 
-def measure_conv_roofline(B, sx_dtype, reps=5):
-    """Replay every conv_ws_kernel launch of a step, in sequence, through the C ABI between HIP events (torch events on
-    the stream the kernels are launched on).  Returns (flops, seconds, launches, bytes): bytes = algorithmic HBM traffic (every input
-    tensor read once, every output written once, packed weights once)."""
+def conv_launch_maker(B, sx_dtype):
+    """make(kind, h, w, cin, cout) -> (launch closure, tensors whose bytes are the algorithmic traffic) for the launches
+    conv_launches() lists; shared with tools/conv_layers.py (the per-layer table under profiles/)."""
     from unet_amd import _lib as L
     lib = L.lib()
     tdt = torch.bfloat16 if sx_dtype == L.SX_BF16 else torch.float32
     g = torch.Generator(device="cuda").manual_seed(0)
-    total_fl, total_s, n, total_by = 0.0, 0.0, 0, 0.0
-    st = torch.cuda.current_stream()
 
     def rnd(*shape):
         return (torch.rand(*shape, device="cuda", generator=g) - 0.5).to(tdt)
@@ -154,6 +151,16 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
                                         cout, h, w, 0, L.ptr(stats), 8 if stats is not None else 0, L.stream_ptr()))
         return launch, (x, y, wp)
 
+    return make
+
+
+def measure_conv_roofline(B, sx_dtype, reps=5):
+    """Replay every conv_ws_kernel launch of a step, in sequence, through the C ABI between HIP events (torch events on
+    the stream the kernels are launched on).  Returns (flops, seconds, launches, bytes): bytes = algorithmic HBM traffic (every input
+    tensor read once, every output written once, packed weights once)."""
+    make = conv_launch_maker(B, sx_dtype)
+    total_fl, total_s, n, total_by = 0.0, 0.0, 0, 0.0
+    st = torch.cuda.current_stream()
     launches = []
     for (kind, h, w, cin, cout, fl) in conv_launches(B):
         launch, tensors = make(kind, h, w, cin, cout)
@@ -368,7 +375,7 @@ def main():
             gbs = nbytes / secs / 1e9
             # aggregate arithmetic intensity fl/nbytes (~180 flop/B) is below the machine balance (2.5 PF / 8 TB/s = 312):
             # the family is bounded by HBM, so that is the roofline quoted; the MFMA view rides along
-            line["roofline"] = {"kernel": "conv_ws_kernel (every launch of one step: 3x3 / 1x1 / transposed forward, 3x3 / 1x1 data gradients)",
+            line["roofline"] = {"kernel": "conv_ws_kernel (every launch of one step: 3x3 / 1x1 / transposed forward, 3x3 / 1x1 / transposed data gradients)",
                                 "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                 "frac": round(gbs / 8000.0, 4), "traffic": conv_traffic(a), "launches_per_step": n,
                                 "bytes_per_step": nbytes, "flops_per_step": fl, "seconds_per_step": round(secs, 6),
