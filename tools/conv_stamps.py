@@ -12,7 +12,7 @@ h, w, cin, cout = int(h), int(w), int(cin), int(cout)
 tdt = torch.bfloat16
 def rnd(*s): return (torch.rand(*s, device="cuda") - 0.5).to(tdt)
 def packed(mode, rows, k): return (rnd(lib.sx_packed_weight_elems(mode, 1, rows, k)) * 0.1).to(tdt)
-stamps = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(1024 * 16, dtype=torch.int64, device="cuda")
 os.environ["SX_WS_STAMPS"] = hex(stamps.data_ptr())
 stats = torch.zeros(B, 8, 2, device="cuda")
 if kind == "dual":
@@ -34,7 +34,7 @@ for it in range(5):
     torch.cuda.synchronize()
     e0.record(); launch(); e1.record()
     torch.cuda.synchronize()
-s = stamps.cpu().view(1024, 8).double()
+s = stamps.cpu().view(1024, 16).double()
 s = s[s[:, 0] > 0]
 print(f"{kind} {h}x{w} {cin}->{cout}: {s.shape[0]} blocks, tiles per block {s[:, 6].min():.0f}..{s[:, 6].max():.0f}, event time {e0.elapsed_time(e1)*1e3:.1f} us")
 t0 = s[:, 0].min()
@@ -44,3 +44,7 @@ for i, nme in enumerate(["entry", "setup done (weights + 3 stages issued)", "fir
 d = s[:, 1:5] - s[:, 0:4]
 for i, nme in enumerate(["setup", "wait first stage", "tile loop", "drain"]):
     print(f"  per-block {nme:18s} median {d[:, i].median():8.0f} max {d[:, i].max():8.0f}")
+loop = (s[:, 3] - s[:, 2])
+nst = s[:, 10].clamp(min=1)
+print(f"  per stage (median block): total {(loop / nst).median():7.0f}  = wait+barrier {(s[:, 7] / nst).median():6.0f} + DMA issue {(s[:, 8] / nst).median():6.0f}"
+      f" + LDS reads/MFMA {((loop - s[:, 7] - s[:, 8] - s[:, 9]) / nst).median():6.0f}; epilogue per tile {(s[:, 9] / s[:, 6].clamp(min=1)).median():6.0f}")

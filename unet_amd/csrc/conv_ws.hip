@@ -15,6 +15,9 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifndef SX_WS_PFD
+#define SX_WS_PFD 1
+#endif
 #ifndef SX_WS_DBG
 #define SX_WS_DBG 0        // 1: in-kernel s_memtime stamps (tools/conv_stamps.py); never in the shipped library
 #endif
@@ -66,6 +69,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   static_assert(VAR != WS_GATHER || (TAPS == 1 && KCH % 4 == 0), "the gather variant is a 1x1 over 4 taps x K chunks");
   constexpr bool GA = VAR == WS_GATHER;
   constexpr bool BS = VAR == WS_BS;
+  constexpr int PFD = SX_WS_PFD;                // fragment rows in flight ahead of the MFMAs
+  constexpr int SWZ_SH = (TWL == 3 && TAPS == 9) ? 1 : 2;     // halo-column bit that flips the channel-group pair (bank swizzle)
   // (block-output sums -- four per channel, FiLM / dropout factors, for the 1x1 head's data gradient -- were built and
   // measured: 45 us fused against 17 + 26 us for the two launches.  A 1x1 launch is all epilogue, and at one wave per SIMD
   // nothing hides the sigmoid's latency; the stand-alone reduction runs the same arithmetic at 8 waves per SIMD.)
@@ -146,16 +151,27 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     const int p = tid + q * 256;
     const int r = p >> 2;
     const int ly = r / LW, lx = r - ly * LW;
+    // LDS slot (pixel r, 16-byte part p&3) holds channel group part ^ swz(lx): see SWZ_SH below
+    const int gpart = (p & 3) ^ (((lx >> SWZ_SH) & 1) << 1);
     if constexpr (GA) {        // stage kk = 4*kc + tap of output pixel (ly, lx): input pixel (2*ly + tap/2, 2*lx + tap%2)
       st_lx[q] = p < PIECES ? 2 * lx : -100000;
-      st_rel[q] = 2 * ly * row_bytes + 2 * lx * a.x_ld * 2 + (p & 3) * 16;
+      st_rel[q] = 2 * ly * row_bytes + 2 * lx * a.x_ld * 2 + gpart * 16;
     } else {
       st_lx[q] = p < PIECES ? lx - PAD : -100000;
-      st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + (p & 3) * 16;
+      st_rel[q] = (ly - PAD) * row_bytes + (lx - PAD) * a.x_ld * 2 + gpart * 16;
     }
   }
   const int nr = n >> TWL, nc = n & (TW - 1);      // this lane's pixel inside a fragment
-  const int frag_off = ((wn * NI * RPF + nr) * LW + nc) * 64 + g * 16;
+  // Fragment reads: lane (n, g) wants the 8 channels of group g of its pixel.  With the groups at their natural 16-byte
+  // parts, each of ds_read_b128's four 16-lane groups hit every 16-byte slot of the 256-byte bank row twice (8 LDS cycles
+  // per read instead of 4: the C >= 128 stages are LDS-read-bound).  Storing group g of halo column lx at part
+  // g ^ 2*bit(lx) -- bit 2 of lx for 16-wide tiles and 8-wide 1x1 tiles, bit 1 for the 10-wide halo of 8-wide 3x3 tiles -- makes
+  // every group cover all 16 slots (enumerated over all rows / taps: tools/lds_bank_model.py).  The LDS-DMA applies the
+  // permutation for free by choosing which global piece a lane fetches; a reading lane's column is nc + tx.
+  int frag_off[TAPW];
+#pragma unroll
+  for (int tx = 0; tx < TAPW; ++tx)
+    frag_off[tx] = ((wn * NI * RPF + nr) * LW + nc) * 64 + ((g ^ ((((nc + tx) >> SWZ_SH) & 1) << 1)) * 16);
 
   TilePos ip;                     // issue position
   ip.set(t_begin, a.tiles_x, a.tiles_y);
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
     __builtin_amdgcn_s_barrier();            // sm_stat may be rewritten by the next flush
   };
 
+  unsigned long long dbg_wait = 0, dbg_issue = 0, dbg_epi = 0, dbg_last = 0;
   for (int t = t_begin; t < t_end; ++t) {
     f32x4 acc[MI][NI], acc2[VAR == WS_DUAL ? MI : 1][VAR == WS_DUAL ? NI : 1];
     // register-heavy instantiations (288 weight VGPRs and two channel fragments per wave) prefetch the first fragment row
@@ -327,10 +344,12 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
 
 #pragma unroll
     for (int kc = 0; kc < KTOT; ++kc, ++s) {
+      const unsigned long long d0 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
       wait_vmcnt<(DIST - 1) * NP>();                 // this wave's pieces of stage s have landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
-      if (WS_DBG && s == 0) t_first = __builtin_amdgcn_s_memtime();
+      const unsigned long long d1 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
+      if (WS_DBG && s == 0) t_first = d1;
       if constexpr (BS) {
         // the GroupNorm input at this tile's output pixels, fetched under the last stage's MFMAs.  Issued BEFORE the stage's
         // DMA: vmcnt retires in order, so waiting for these loads later must not wait for the newest prefetch stage too
@@ -351,12 +370,14 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         }
       }
       issue_stage();                                 // stage s + DIST (dummy past the end: keeps vmcnt uniform)
-      const char* buf = smem + (s % NBUF) * BUF + frag_off;
+      const unsigned long long d2 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
+      if (WS_DBG) { dbg_wait += d1 - d0; dbg_issue += d2 - d1; dbg_last = d2; }
+      const char* buf = smem + (s % NBUF) * BUF;
       if constexpr (VAR == WS_CENTER) {
         if (kc >= KCH) {                             // shortcut channels: centre tap only
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const bf16x8 Bc = *reinterpret_cast<const bf16x8*>(buf + ((i * RPF + 1) * LW + 1) * 64);
+            const bf16x8 Bc = *reinterpret_cast<const bf16x8*>(buf + frag_off[1] + ((i * RPF + 1) * LW + 1) * 64);
 #pragma unroll
             for (int j = 0; j < MI; ++j)
               acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[kc - KCH][j], Bc, acc[j][i], 0, 0, 0);
@@ -365,11 +386,24 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
         }
       }
       constexpr int KC = KCH;                        // bound for indexing A (kc < KCH here)
+      // Fragment rows are fetched PFD rows ahead of the MFMAs that consume them (register ring Bq): issued and awaited back
+      // to back -- what the compiler schedules on its own at this register pressure -- every row exposed the full LDS
+      // latency, 18 times per stage at the deep levels (3.7k cycles per stage against 1152 of MFMA, s_memtime stamps).
+      constexpr int NR = NI * RPF + TAPW - 1;        // halo rows of the fragments' first rows
+      bf16x8 Bq[PFD + 1][TAPW];
 #pragma unroll
-      for (int rr = 0; rr < NI * RPF + TAPW - 1; ++rr) {      // halo row of the fragments' first rows
-        bf16x8 Bf[TAPW];
+      for (int p = 0; p < PFD && p < NR; ++p)
 #pragma unroll
-        for (int tx = 0; tx < TAPW; ++tx) Bf[tx] = *reinterpret_cast<const bf16x8*>(buf + (rr * LW + tx) * 64);
+        for (int tx = 0; tx < TAPW; ++tx) Bq[p][tx] = *reinterpret_cast<const bf16x8*>(buf + frag_off[tx] + (p * LW + tx) * 64);
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        if (rr + PFD < NR) {
+#pragma unroll
+          for (int tx = 0; tx < TAPW; ++tx)
+            Bq[(rr + PFD) % (PFD + 1)][tx] = *reinterpret_cast<const bf16x8*>(buf + frag_off[tx] + ((rr + PFD) * LW + tx) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch above this row's MFMAs
+        const bf16x8 (&Bf)[TAPW] = Bq[rr % (PFD + 1)];
 #pragma unroll
         for (int ty = 0; ty < TAPW; ++ty) {
           const int i = (rr - ty) / RPF;
@@ -388,9 +422,11 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
+    const unsigned long long d3 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
     // ---- epilogue of tile t = (cp.b, cp.ty, cp.tx)
     bf16* ytile = yg + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y_ld;   // wave-uniform
     bf16* y2tile = VAR == WS_DUAL ? reinterpret_cast<bf16*>(a.y2) + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y2_ld : nullptr;
@@ -465,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
       }
     }
     }
+    if (WS_DBG) dbg_epi += __builtin_amdgcn_s_memtime() - d3;
     const int b_done = cp.b;
     cp.next(a.tiles_x, a.tiles_y);
     if (do_stats && (t + 1 == t_end || cp.b != b_done)) flush_stats(b_done);
@@ -497,9 +534,10 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
   const unsigned long long t_loop = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
   wait_vmcnt<0>();     // drain the dummy prefetches before the wave (and its LDS allocation) retires
   if (WS_DBG && a.stamps && tid == 0) {
-    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
     o[0] = t_entry; o[1] = t_setup; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
     o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = (unsigned long long)(t_end - t_begin);
+    o[7] = dbg_wait; o[8] = dbg_issue; o[9] = dbg_epi; o[10] = (unsigned long long)nst;   // summed over the block's stages / tiles (wave 0)
   }
 }
 
