@@ -15,6 +15,9 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifndef SX_WS_NBUF
+#define SX_WS_NBUF 4
+#endif
 #ifndef SX_WS_PFD
 #define SX_WS_PFD 1
 #endif
@@ -53,7 +56,7 @@ struct TilePos {
 // than 16, the deepest U-Net levels): a fragment = two rows of 8.
 // VAR: WS_PLAIN / WS_DUAL / WS_CENTER (conv_common.h): the 1x1 shortcut of a DoubleConv block rides along with the 3x3.
 template <int KCH, int TAPS, int MI, int NI, int WM, int WN, int NBUF, int TWL, int VAR>
-__global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArgs a) {     // 3-stage ring = the two-blocks-per-CU form
   constexpr int TAPW = TAPS == 9 ? 3 : 1;
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int BMC = WM * MI * 16;
@@ -548,7 +551,17 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr int BMC = WM * MI * 16, TH = WN * NI * (16 / TW);
   constexpr int NPIX = (TH + TAPW - 1) * (TW + TAPW - 1);
   constexpr int NP = (NPIX * 4 + 255) / 256;
-  constexpr int NBUF = 4;                                       // three stages in flight per block
+  // Light configurations (few weight registers, 8 or more tiles per block) run TWO blocks per CU with a 3-stage ring each
+  // (<= 80 KB of LDS, < 256 VGPRs): the second wave on a SIMD hides the LDS latency the first one cannot (profiles/
+  // r02_conv_ws_stamps.txt).  Measured per configuration (tools/conv_layers.py, SX_WS_PER_CU=2 against 1): level-0 3x3
+  // 22.4 -> 19.9 us, level-0 / level-1 joint data gradients 34.4 -> 30.2 and 29.4 -> 23.5, 1x1 head 15.3 -> 11.8,
+  // transposed forward at 64x32 18.4 -> 16.7, level-0 fused-sums data gradient 30.0 -> 26.9 (all 32-channel 3x3 forms
+  // once __launch_bounds__(256, 2) keeps them under 256 VGPRs); the 64-channel forms spill 300-400 bytes per lane at that
+  // budget (21 -> 40 us) and the deeper ones have too few tiles per block: they keep one block per CU.
+  constexpr bool TWO = (TAPS == 9 && KCH == 1 && MI == 2 && NI == 4 && TWL == 4) ||
+                       (VAR == WS_CENTER && ((KCH == 1 && MI == 2) || (KCH == 2 && MI == 1 && NI == 8 && TWL == 4))) ||
+                       (VAR == WS_PLAIN && TAPS == 1 && KCH <= 2 && TWL == 4);
+  constexpr int NBUF = TWO ? 3 : SX_WS_NBUF;                    // NBUF - 1 stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * (VAR == WS_BS ? 4 : 2) * sizeof(float);
   auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL, VAR>;
   static std::atomic<unsigned long long> done{0};
@@ -560,7 +573,8 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   const int ntiles = a.B * a.tiles_x * a.tiles_y;
   const int gy = cdiv(a.RTot, BMC);
   // persistent grid: about one block per CU (registers allow one wave per SIMD); light variants get two
-  static const int per_cu = std::max(1, env_int("SX_WS_PER_CU", 1));     // tuning knob, read once per process
+  static const int per_cu_env = env_int("SX_WS_PER_CU", 0);     // tuning knob (0 = the per-configuration choice), read once per process
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (TWO ? 2 : 1);
   int gx = std::max(1, std::min(ntiles, (256 * per_cu) / gy));
   gx = cdiv(ntiles, cdiv(ntiles, gx));       // contiguous tile ranges: no empty trailing blocks
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, a);
