@@ -559,7 +559,8 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   // once __launch_bounds__(256, 2) keeps them under 256 VGPRs); the 64-channel forms spill 300-400 bytes per lane at that
   // budget (21 -> 40 us) and the deeper ones have too few tiles per block: they keep one block per CU.
   constexpr bool TWO = (TAPS == 9 && KCH == 1 && MI == 2 && NI == 4 && TWL == 4) ||
-                       (VAR == WS_CENTER && ((KCH == 1 && MI == 2) || (KCH == 2 && MI == 1 && NI == 8 && TWL == 4))) ||
+                       (VAR == WS_CENTER && KCH == 1 && MI == 2) || (TAPS == 9 && KCH == 2 && MI == 1 && NI == 8 && TWL == 4 && VAR != WS_DUAL) ||
+                       (TAPS == 9 && KCH == 4 && MI == 1 && NI == 8 && TWL == 4 && VAR == WS_PLAIN) ||
                        (VAR == WS_PLAIN && TAPS == 1 && KCH <= 2 && TWL == 4);
   constexpr int NBUF = TWO ? 3 : SX_WS_NBUF;                    // NBUF - 1 stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * (VAR == WS_BS ? 4 : 2) * sizeof(float);
@@ -603,12 +604,18 @@ static int ws_pick_tile(const ConvArgs& a, hipStream_t st) {
     else if constexpr (LIGHT) return launch_ws<KCH, TAPS, 1, 4, 2, 2, 4, VAR>(a, st);   // 32 ch x 128 px
     else return launch_ws<KCH, TAPS, 2, 4, 1, 4, 4, VAR>(a, st);                        // 32 ch x 256 px (16 rows)
   } else if (a.RTot <= 64) {
-    if constexpr (KCH <= 4 && !LIGHT) return launch_ws<KCH, TAPS, 2, 4, 2, 2, 4, VAR>(a, st);   // 64 ch x 128 px (8 rows)
+    // 64 input channels: 16-channel wave tiles (72 weight registers) fit two blocks per CU: 17.6 -> 15.9 us, with the
+    // fused sums 21.7 -> 18.5 us against the 32-channel wave tiles at one block per CU
+    if constexpr (KCH == 2 && TAPS == 9 && (VAR == WS_PLAIN || VAR == WS_BS)) return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);
+    else if constexpr (KCH <= 4 && !LIGHT) return launch_ws<KCH, TAPS, 2, 4, 2, 2, 4, VAR>(a, st);   // 64 ch x 128 px (8 rows)
     else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                                // 64 ch x 128 px
   } else {
     // (the fused-sums variant of the 288-weight-register tile spills and its one-tile blocks expose all of the extra
     // arithmetic: measured 37.6 us against 19.9 + 10 us for convolution + separate reduction -> two launches there)
+    // 128 input channels: 16-channel wave tiles, two blocks per CU (16.5 -> 15.6 us against 32-channel wave tiles)
+    // (its fused-sums form spills 184 bytes per lane at the two-block register budget: step 1.728 against 1.720 ms)
     if constexpr (VAR == WS_BS && KCH * TAPS * 2 * 4 >= 288) return 1;
+    else if constexpr (KCH == 4 && VAR == WS_PLAIN && TAPS == 9) return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);
     else if constexpr (KCH <= 4 && (VAR == WS_PLAIN || VAR == WS_BS)) return launch_ws<KCH, TAPS, 2, 8, 4, 1, 4, VAR>(a, st);   // 128 ch x 128 px
     else return launch_ws<KCH, TAPS, 1, 8, 4, 1, 4, VAR>(a, st);                      // 64 ch x 128 px, grid.y = RTot/64
   }
