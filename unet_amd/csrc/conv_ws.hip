@@ -557,10 +557,11 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   // 22.4 -> 19.9 us, level-0 / level-1 joint data gradients 34.4 -> 30.2 and 29.4 -> 23.5, 1x1 head 15.3 -> 11.8,
   // transposed forward at 64x32 18.4 -> 16.7, level-0 fused-sums data gradient 30.0 -> 26.9 (all 32-channel 3x3 forms
   // once __launch_bounds__(256, 2) keeps them under 256 VGPRs); the 64-channel forms spill 300-400 bytes per lane at that
-  // budget (21 -> 40 us) and the deeper ones have too few tiles per block: they keep one block per CU.
+  // budget (21 -> 40 us; the 128-channel fused-shortcut forward 27 -> 49 us) and the deeper ones have too few tiles per
+  // block: they keep one block per CU.  128-channel joint gradient 24.9 -> 22.9, 64-channel fused forward 15.3 -> 14.5 us.
   constexpr bool TWO = (TAPS == 9 && KCH == 1 && MI == 2 && NI == 4 && TWL == 4) ||
-                       (VAR == WS_CENTER && KCH == 1 && MI == 2) || (TAPS == 9 && KCH == 2 && MI == 1 && NI == 8 && TWL == 4 && VAR != WS_DUAL) ||
-                       (TAPS == 9 && KCH == 4 && MI == 1 && NI == 8 && TWL == 4 && VAR == WS_PLAIN) ||
+                       (VAR == WS_CENTER && KCH == 1 && MI == 2) || (TAPS == 9 && KCH == 2 && MI == 1 && NI == 8 && TWL == 4) ||
+                       (TAPS == 9 && KCH == 4 && MI == 1 && NI == 8 && TWL == 4 && (VAR == WS_PLAIN || VAR == WS_CENTER)) ||
                        (VAR == WS_PLAIN && TAPS == 1 && KCH <= 2 && TWL == 4);
   constexpr int NBUF = TWO ? 3 : SX_WS_NBUF;                    // NBUF - 1 stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * (VAR == WS_BS ? 4 : 2) * sizeof(float);
