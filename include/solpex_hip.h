@@ -56,7 +56,9 @@ const char* sx_last_error(void);
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Replaces nothing in the reference (ATen consumes (Cout,Cin,kh,kw) directly);
  * the MFMA kernels want K-contiguous, zero-padded tiles in the activation dtype:
- *   fp32: packed[tap][CoutPad][CinPad], CoutPad = roundup(Cout,16), CinPad = roundup(Cin, 16);
+ *   fp32: CoutPad = roundup(Cout,16), CinPad = roundup(Cin, 32); in the default split-bf16 arithmetic (below) every
+ *         (tap, row, 32-k chunk) holds 32 bf16 hi values followed by the 32 lo values (hi = bf16(w), lo = bf16(w - hi)),
+ *         in the exact mode packed[tap][CoutPad][CinPad] fp32 -- the same number of bytes;
  *   bf16: the same elements (CinPad = roundup(Cin, 32)) in 1 KB units of 16 rows x 32 k, unit order
  *         [row/16][k/32][tap], 16-byte group (row, 8 k) at lane ((k%32)/8)*16 + row%16 inside a unit: each unit is one
  *         contiguous wave load in MFMA A-operand order (conv_common.h: wpack_off_bf16).  The layout is private to the
@@ -66,6 +68,17 @@ const char* sx_last_error(void);
  * sx_packed_weight_elems() returns the element count of the packed tensor.
  * --------------------------------------------------------------------------------------------- */
 int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k);
+
+/* fp32 arithmetic of sx_conv_forward / sx_conv_wgrad (and everything built on them).  Tensors are fp32 in HBM either way.
+ *   default (split-bf16): each fp32 operand v is split into bf16 hi + lo on its way into LDS and a product block is three
+ *     v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulation): <= 1.1e-5 relative error per product, 4e-6
+ *     relative L2 on a whole convolution (TF32, cuDNN's default for the reference's fp32 convolutions, carries 4.9e-4),
+ *     at 3/16 of the matrix-core time of exact fp32;
+ *   exact: v_mfma_f32_16x16x4_f32 throughout (environment SX_FP32_EXACT=1 at start-up, or this call).
+ * Returns the previous setting (1 = exact).  Packed fp32 weights are specific to the mode they were packed in: repack
+ * after a switch.  Process-wide; do not switch while calls are in flight on other threads.  No counterpart in the
+ * reference (torch.backends.cudnn.allow_tf32 is the closest knob). */
+int sx_set_fp32_exact(int on);
 int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
                         void* packed, void* stream);
 

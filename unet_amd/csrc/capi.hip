@@ -34,7 +34,23 @@ int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+
+// fp32 arithmetic of the convolution kernels: 1 = split-bf16 (three bf16 MFMAs per product block), 0 = exact fp32 MFMA
+static std::atomic<int> g_fp32_split{-1};
+int fp32_split() {
+  int v = g_fp32_split.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = env_int("SX_FP32_EXACT", 0) ? 0 : 1;
+    g_fp32_split.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 }  // namespace sx
 
+extern "C" int sx_set_fp32_exact(int on) {
+  const int was = sx::fp32_split() ? 0 : 1;
+  sx::g_fp32_split.store(on ? 0 : 1, std::memory_order_relaxed);
+  return was;
+}
 extern "C" int sx_version(void) { return SX_VERSION; }
 extern "C" const char* sx_last_error(void) { return sx::g_err; }

@@ -15,6 +15,13 @@ __host__ __device__ inline int64_t wpack_off_bf16(int ntaps, int kchunks, int ta
   return ((((int64_t)(row >> 4) * kchunks + (k >> 5)) * ntaps + tap) << 9) + (((((k & 31) >> 3) << 4) + (row & 15)) << 3) + (k & 7);
 }
 
+// fp32 tier in split form (conv_x3.hip): per (tap, row, 32-k chunk) 32 bf16 hi values followed by the 32 lo values
+// (hi = bf16(w), lo = bf16(w - hi)); same bytes as the plain fp32 pack [tap][row][k].  Index of the hi value in bf16
+// elements, the lo value sits 32 elements further.
+__host__ __device__ inline int64_t wpack_off_x3(int RTot, int kchunks, int tap, int row, int k) {
+  return ((((int64_t)tap * RTot + row) * kchunks + (k >> 5)) << 6) + (k & 31);
+}
+
 struct ConvArgs {
   const void* x; const void* w; void* y; const float* bias; float* gn_stats;
   int B, H, W;
@@ -73,6 +80,7 @@ template <> struct Mma<float> {
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
 enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3, WS_GATHER = 4 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
+int conv_x3_dispatch(const ConvArgs& a, hipStream_t st);      // fp32 tensors, split-bf16 arithmetic (conv_x3.hip)
 
 // Weight packing for a whole table of layers in one launch (conv_igemm.hip).
 struct PackDesc {
@@ -84,7 +92,7 @@ struct PackDesc {
 static constexpr int PACK_MAX = 56;
 // pad: optional zero-padded fp32 copy out[i] = i < n ? src[i] : 0 for i < npad <= 256 (the head's bias), done by block 0
 struct PackPad { const float* src; float* dst; int n, npad; };
-struct PackArgs { PackDesc d[PACK_MAX]; int n; PackPad pad; };
+struct PackArgs { PackDesc d[PACK_MAX]; int n; PackPad pad; int split; };
 int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d);
 int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad = nullptr);
 

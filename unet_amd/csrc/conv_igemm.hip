@@ -283,7 +283,12 @@ __global__ void pack_weight_kernel(PackArgs A) {
       if (row < Cin && k < Cout) v = w[((int64_t)row * Cout + k) * 4 + tap];
     }
     if constexpr (sizeof(T) == 2) out[wpack_off_bf16((int)(D.total / ((int64_t)RTot * KPad)), KPad >> 5, tap, row, k)] = from_f32<T>(v);
-    else out[idx] = from_f32<T>(v);
+    else if (A.split) {
+      bf16* o2 = reinterpret_cast<bf16*>(D.out) + wpack_off_x3(RTot, KPad >> 5, tap, row, k);
+      const bf16 h = (bf16)v;
+      o2[0] = h;
+      o2[32] = (bf16)(v - (float)h);
+    } else out[idx] = from_f32<T>(v);
   }
 }
 
@@ -298,10 +303,19 @@ struct PackPair {
   int blk0, tiles_ci;
 };
 static constexpr int PAIR_MAX = 32;
-struct PackPairArgs { PackPair d[PAIR_MAX]; int n; };
+struct PackPairArgs { PackPair d[PAIR_MAX]; int n; int split; };
+
+// 8 consecutive k of one row as 8 hi + 8 lo bf16 (wpack_off_x3)
+__device__ __forceinline__ void store8_split(bf16* p, const f32x8& r) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { h[i] = (bf16)r.v[i]; l[i] = (bf16)(r.v[i] - (float)h[i]); }
+  *reinterpret_cast<bf16x8*>(p) = h;
+  *reinterpret_cast<bf16x8*>(p + 32) = l;
+}
 
 template <typename T, int NT>
-__device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int ci0, float (*tile)[32 * 9 + 1]) {
+__device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int ci0, float (*tile)[32 * 9 + 1], bool split) {
   constexpr int RUN = 32 * NT, TOTAL = 32 * RUN, U = 4;
   // U independent loads in flight per thread (a block is 36 trips of one load otherwise, on ~1 block per CU)
   for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * U) {
@@ -332,6 +346,7 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[hi][(lo8 + i) * NT + tap];
         if constexpr (sizeof(T) == 2) store8(of + wpack_off_bf16(NT, D.KPad_f >> 5, tap, co, ci), v);
+        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_f) + wpack_off_x3(D.RTot_f, D.KPad_f >> 5, tap, co, ci), v);
         else store8(of + ((int64_t)tap * D.RTot_f + co) * D.KPad_f + ci, v);
       }
     }
@@ -341,6 +356,7 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[lo8 + i][hi * NT + tap];
         if constexpr (sizeof(T) == 2) store8(ot + wpack_off_bf16(NT, D.KPad_t >> 5, NT - 1 - tap, ci, co), v);
+        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_t) + wpack_off_x3(D.RTot_t, D.KPad_t >> 5, NT - 1 - tap, ci, co), v);
         else store8(ot + ((int64_t)(NT - 1 - tap) * D.RTot_t + ci) * D.KPad_t + co, v);
       }
     }
@@ -355,13 +371,13 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairArgs A) {
   const PackPair& D = A.d[di];
   const int tb = (int)blockIdx.x - D.blk0;
   const int co0 = (tb / D.tiles_ci) * 32, ci0 = (tb % D.tiles_ci) * 32;
-  if (D.nt == 9) pack_pair_tile<T, 9>(D, co0, ci0, tile);
-  else pack_pair_tile<T, 1>(D, co0, ci0, tile);
+  if (D.nt == 9) pack_pair_tile<T, 9>(D, co0, ci0, tile, A.split != 0);
+  else pack_pair_tile<T, 1>(D, co0, ci0, tile, A.split != 0);
 }
 
 struct PackGeom { int ntaps, R, K, RPad, RTot, KPad; };
 static PackGeom pack_geom(int mode, int dtype, int tflip, int Cout, int Cin) {
-  const int CK = dtype == SX_BF16 ? 32 : 16;
+  const int CK = 32;       // both tiers pad K to 32 (fp32: the split form walks 32-channel chunks, the exact form 16)
   PackGeom p;
   if (mode == SX_CONV3 || mode == SX_CONV1) {
     p.ntaps = mode == SX_CONV3 ? 9 : 1;
@@ -384,7 +400,7 @@ using namespace sx;
 
 extern "C" int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k) {
   // c_rows / c_k are the GEMM's output / reduction channel counts (after any transpose).
-  const int CK = dtype == SX_BF16 ? 32 : 16;
+  const int CK = 32;
   const int ntaps = mode == SX_CONV3 ? 9 : (mode == SX_CONVT_BWD ? 4 : 1);
   const int rtot = round_up(c_rows, 16) * (mode == SX_CONVT_FWD ? 4 : 1);
   return (int64_t)ntaps * rtot * round_up(c_k, CK);
@@ -424,6 +440,7 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, 
   }
   for (size_t i0 = 0; i0 < pairs.size(); i0 += PAIR_MAX) {
     PackPairArgs A;
+    A.split = dtype == SX_F32 && fp32_split();
     A.n = (int)std::min<size_t>(PAIR_MAX, pairs.size() - i0);
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
@@ -445,6 +462,7 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, 
   for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
     PackArgs A;
     memset(&A.pad, 0, sizeof(A.pad));
+    A.split = dtype == SX_F32 && fp32_split();
     if (pad && i0 == 0) A.pad = *pad;
     A.n = std::min(PACK_MAX, n - i0);
     int blk = 0;
@@ -477,7 +495,7 @@ extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin
   SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_forward: bad dtype %d", dtype);
   SX_REQUIRE(mode >= SX_CONV3 && mode <= SX_CONVT_BWD, "sx_conv_forward: bad mode %d", mode);
   SX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sx_conv_forward: empty problem");
-  const int EPL = dtype == SX_BF16 ? 8 : 4, CK = dtype == SX_BF16 ? 32 : 16;
+  const int EPL = dtype == SX_BF16 ? 8 : 4, CK = 32;
   if (Cin % EPL || x_ld % EPL || Cout % 4 || y_ld % 4) {
     set_error("sx_conv_forward: channel counts must be multiples of %d (in) / 4 (out): Cin=%d x_ld=%d Cout=%d y_ld=%d",
               EPL, Cin, x_ld, Cout, y_ld);
@@ -522,6 +540,7 @@ extern "C" int sx_conv_forward(int dtype, int mode, int B, int H, int W, int Cin
     const int rc = conv_ws_try(a, mode, st);   // 0 = launched, 1 = shape not covered, <0 = error
     if (rc <= 0) return rc;
   }
+  if (dtype == SX_F32 && fp32_split()) return conv_x3_dispatch(a, st);
   return dtype == SX_BF16 ? conv_dispatch<bf16>(a, st) : conv_dispatch<float>(a, st);
 }
 

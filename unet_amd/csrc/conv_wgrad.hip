@@ -245,6 +245,160 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// fp32 tier on the bf16 matrix cores (see conv_x3.hip): both operand tiles are split into bf16 hi / lo planes on their way
+// into LDS (pixel-major rows, exactly the images of the bf16 branch above, two of each), fragments come through
+// ds_read_b64_tr_b16 and every product block is three MFMAs: lo*hi + hi*lo + hi*hi.  The next tile's pieces are fetched
+// into registers under this tile's MFMAs.
+template <int MI, int ITEMS>
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
+  constexpr int BA = MI * 16, BB = 64;
+  constexpr int PROW = BA * 2 + 16, QROW = BB * 2 + 16;
+  constexpr int PPIECES = BA / 4, QPIECES = BB / 4;        // 16-byte pieces of 4 fp32 per pixel
+  constexpr int NPP = 4, NPQ = 8;
+  extern __shared__ __align__(16) char smem[];
+  char* sPh = smem;
+  char* sPl = sPh + a.TP * PROW;
+  char* sQh = sPl + a.TP * PROW;
+  char* sQl = sQh + a.LH * a.LW * QROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
+  const int split = blockIdx.z;
+  const int nitems = a.ntaps * a.nbf;
+
+  int it_tap_off[ITEMS], it_bf[ITEMS];
+  bool it_valid[ITEMS];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    const int it = wid * ITEMS + t;
+    it_valid[t] = it < nitems;
+    const int itc = it_valid[t] ? it : 0;
+    const int tap = itc / a.nbf;
+    it_bf[t] = itc - tap * a.nbf;
+    const int tyy = tap / a.tapw, txx = tap - tyy * a.tapw;
+    it_tap_off[t] = (tyy * a.LW + txx) * QROW;
+  }
+  f32x4 acc[ITEMS][MI];
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* __restrict__ Pg = reinterpret_cast<const float*>(a.P);
+  const float* __restrict__ Qg = reinterpret_cast<const float*>(a.Q);
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  f32x4 pre_p[NPP], pre_q[NPQ];
+  int pp_y[NPP], pp_x[NPP], pq_y[NPQ], pq_x[NPQ];
+  const int np_p = a.TP * PPIECES, np_q = a.LH * a.LW * QPIECES;
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int p = tid + i * 256, m = p / PPIECES;
+    pp_y[i] = p < np_p ? (m >> a.tw_log2) : (1 << 28);       // out-of-range pieces fail every bounds test
+    pp_x[i] = m & (a.TW - 1);
+  }
+#pragma unroll
+  for (int i = 0; i < NPQ; ++i) {
+    const int p = tid + i * 256, r = p / QPIECES;
+    pq_y[i] = p < np_q ? r / a.LW : (1 << 28);
+    pq_x[i] = r - (r / a.LW) * a.LW;
+  }
+  auto fetch = [&](int tile) {
+    int tt = tile;
+    const int tx_i = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty_i = tt % a.tiles_y; tt /= a.tiles_y;
+    const int bimg = tt;
+    const int ty0 = ty_i * a.TH, tx0 = tx_i * a.TW;
+    const int qy0 = ty0 * a.q_scale - a.pad, qx0 = tx0 * a.q_scale - a.pad;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int py = ty0 + pp_y[i], px = tx0 + pp_x[i];
+      const int c = a0 + ((tid + i * 256) % PPIECES) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (py < a.H && px < a.W && c < a.Ca)
+        v = *reinterpret_cast<const f32x4*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
+      pre_p[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int qy = qy0 + pq_y[i], qx = qx0 + pq_x[i];
+      const int c = b0 + ((tid + i * 256) % QPIECES) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
+        v = *reinterpret_cast<const f32x4*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
+      pre_q[i] = v;
+    }
+  };
+  auto put = [&](char* hi_img, char* lo_img, int off, const f32x4& v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (bf16)v[e]; l[e] = (bf16)(v[e] - (float)h[e]); }
+    *reinterpret_cast<bf16x4*>(hi_img + off) = h;
+    *reinterpret_cast<bf16x4*>(lo_img + off) = l;
+  };
+  fetch(t_begin);
+  const int q4 = n >> 2, p4 = n & 3;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int p = tid + i * 256;
+      if (p < np_p) put(sPh, sPl, (p / PPIECES) * PROW + (p % PPIECES) * 8, pre_p[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int p = tid + i * 256;
+      if (p < np_q) put(sQh, sQl, (p / QPIECES) * QROW + (p % QPIECES) * 8, pre_q[i]);
+    }
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
+    for (int ks = 0; ks < (a.TP >> 5); ++ks) {
+      // this lane supplies rows k = ks*32 + 8g + 4jb + q4, jb = 0,1
+      const int k0 = ks * 32 + 8 * g + q4, k1 = k0 + 4;
+      const int pa0 = k0 * PROW + p4 * 8, pa1 = k1 * PROW + p4 * 8;
+      bf16x8 Ah[MI], Al[MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        Ah[j] = Frag<bf16>::read(sPh + pa0 + j * 32, sPh + pa1 + j * 32);
+        Al[j] = Frag<bf16>::read(sPl + pa0 + j * 32, sPl + pa1 + j * 32);
+      }
+      const int r0 = (((k0 >> a.tw_log2) * a.q_scale) * a.LW + (k0 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
+      const int r1 = (((k1 >> a.tw_log2) * a.q_scale) * a.LW + (k1 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
+#pragma unroll
+      for (int t = 0; t < ITEMS; ++t) {
+        // every lane issues the transposed reads (EXEC must be full); invalid items read item 0
+        const int o0 = r0 + it_tap_off[t] + it_bf[t] * 32, o1 = r1 + it_tap_off[t] + it_bf[t] * 32;
+        const bf16x8 Bh = Frag<bf16>::read(sQh + o0, sQh + o1);
+        const bf16x8 Bl = Frag<bf16>::read(sQl + o0, sQl + o1);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh, acc[t][j], 0, 0, 0);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl, acc[t][j], 0, 0, 0);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh, acc[t][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* slab = a.slab + (int64_t)split * a.ntaps * a.CaPad * a.CbPad;
+#pragma unroll
+  for (int t = 0; t < ITEMS; ++t) {
+    if (!it_valid[t]) continue;
+    const int it = wid * ITEMS + t;
+    const int tap = it / a.nbf, bf = it - tap * a.nbf;
+    const int bcol = b0 + bf * 16 + n;
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int arow = a0 + j * 16 + 4 * g + r;
+        if (arow < a.CaPad && bcol < a.CbPad)
+          slab[((int64_t)tap * a.CaPad + arow) * a.CbPad + bcol] = acc[t][j][r];
+      }
+  }
+}
+
 // out[(a*Cb + b)*ntaps + tap] (+)= sum_s slab[s][tap][a][b]   (PyTorch layouts: conv W[co][ci][tap], convT W[ci][co][tap])
 // One launch reduces the slabs of many layers (descriptor table in the kernel arguments).  Unit of work = one
 // 256-byte segment of a slab row (64 consecutive b) x all splits: 16 threads x float4 along b, 16 split lanes whose
@@ -413,6 +567,37 @@ static int wgrad_items(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
   return SX_ERR_UNSUPPORTED;
 }
 
+template <int MI, int ITEMS>
+static int launch_wgrad_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
+  constexpr int PROW = MI * 16 * 2 + 16, QROW = 64 * 2 + 16;
+  const size_t smem = 2 * ((size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW);
+  if (smem > 160 * 1024) { set_error("wgrad tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
+  if (a.TP * MI * 4 > 4 * 256 || a.LH * a.LW * 16 > 8 * 256 || a.TP % 32) {     // the kernel's register-prefetch slots
+    set_error("wgrad: fp32 tile of %d + %d pixels exceeds the prefetch slots", a.TP, a.LH * a.LW);
+    return SX_ERR_UNSUPPORTED;
+  }
+  auto kern = wgrad_x3_kernel<MI, ITEMS>;
+  static std::atomic<unsigned long long> done{0};
+  SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(wgrad_x3)"));
+  hipLaunchKernelGGL(kern, dim3(p.a_tiles, p.b_tiles, p.nsplit), dim3(256), smem, st, a);
+  SX_LAUNCH_CHECK("wgrad_x3");
+  return SX_OK;
+}
+
+template <int MI>
+static int wgrad_items_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
+  switch (p.items) {
+    case 1: return launch_wgrad_x3<MI, 1>(a, p, st);
+    case 2: return launch_wgrad_x3<MI, 2>(a, p, st);
+    case 3: return launch_wgrad_x3<MI, 3>(a, p, st);
+    case 4: return launch_wgrad_x3<MI, 4>(a, p, st);
+    case 5: return launch_wgrad_x3<MI, 5>(a, p, st);
+    case 9: return launch_wgrad_x3<MI, 9>(a, p, st);
+  }
+  set_error("wgrad: unexpected item count %d", p.items);
+  return SX_ERR_UNSUPPORTED;
+}
+
 }  // namespace sx
 
 using namespace sx;
@@ -465,6 +650,7 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
   a.nbf = p.nbf; a.tiles_per_split = p.tiles_per_split;
   int rc;
   if (dtype == SX_BF16) rc = p.MI == 4 ? wgrad_items<bf16, 4>(a, p, st) : wgrad_items<bf16, 2>(a, p, st);
+  else if (fp32_split()) rc = p.MI == 4 ? wgrad_items_x3<4>(a, p, st) : wgrad_items_x3<2>(a, p, st);
   else rc = p.MI == 4 ? wgrad_items<float, 4>(a, p, st) : wgrad_items<float, 2>(a, p, st);
   SX_TRY(rc);
   desc->slab = (const float*)slab; desc->nsplit = p.nsplit; desc->ntaps = a.ntaps; desc->CaPad = a.CaPad; desc->CbPad = a.CbPad;

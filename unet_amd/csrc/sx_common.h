@@ -155,6 +155,10 @@ int ensure_max_lds(const void* kern, std::atomic<unsigned long long>& done, cons
 // integer tuning knob from the environment (callers keep the result in a function-local static: read once per process)
 int env_int(const char* name, int dflt);
 
+// 1: fp32 convolutions and weight gradients run as three bf16 MFMAs on split operands (default; conv_x3.hip); 0: exact
+// fp32 MFMA (SX_FP32_EXACT=1 or sx_set_fp32_exact).  The packed fp32 weights differ between the two: repack after a switch.
+int fp32_split();
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
