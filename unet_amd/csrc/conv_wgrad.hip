@@ -249,12 +249,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // into LDS (pixel-major rows, exactly the images of the bf16 branch above, two of each), fragments come through
 // ds_read_b64_tr_b16 and every product block is three MFMAs: lo*hi + hi*lo + hi*hi.  The next tile's pieces are fetched
 // into registers under this tile's MFMAs.
-template <int MI, int ITEMS>
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
+// NW waves per block: the 36 items of a 64 x 64 x 9 problem take 9 x 16 accumulator registers per wave on four waves (spills at
+// two blocks per CU); on eight waves they take 5 x 16.
+template <int MI, int ITEMS, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(WgradArgs a) {
+  constexpr int NT = NW * 64;
   constexpr int BA = MI * 16, BB = 64;
   constexpr int PROW = BA * 2 + 16, QROW = BB * 2 + 16;
   constexpr int PPIECES = BA / 4, QPIECES = BB / 4;        // 16-byte pieces of 4 fp32 per pixel
-  constexpr int NPP = 4, NPQ = 8;
+  constexpr int NPP = 1024 / NT, NPQ = 2048 / NT;
   extern __shared__ __align__(16) char smem[];
   char* sPh = smem;
   char* sPl = sPh + a.TP * PROW;
@@ -294,13 +297,13 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
   const int np_p = a.TP * PPIECES, np_q = a.LH * a.LW * QPIECES;
 #pragma unroll
   for (int i = 0; i < NPP; ++i) {
-    const int p = tid + i * 256, m = p / PPIECES;
+    const int p = tid + i * NT, m = p / PPIECES;
     pp_y[i] = p < np_p ? (m >> a.tw_log2) : (1 << 28);       // out-of-range pieces fail every bounds test
     pp_x[i] = m & (a.TW - 1);
   }
 #pragma unroll
   for (int i = 0; i < NPQ; ++i) {
-    const int p = tid + i * 256, r = p / QPIECES;
+    const int p = tid + i * NT, r = p / QPIECES;
     pq_y[i] = p < np_q ? r / a.LW : (1 << 28);
     pq_x[i] = r - (r / a.LW) * a.LW;
   }
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
       const int py = ty0 + pp_y[i], px = tx0 + pp_x[i];
-      const int c = a0 + ((tid + i * 256) % PPIECES) * 4;
+      const int c = a0 + ((tid + i * NT) % PPIECES) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (py < a.H && px < a.W && c < a.Ca)
         v = *reinterpret_cast<const f32x4*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NPQ; ++i) {
       const int qy = qy0 + pq_y[i], qx = qx0 + pq_x[i];
-      const int c = b0 + ((tid + i * 256) % QPIECES) * 4;
+      const int c = b0 + ((tid + i * NT) % QPIECES) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
         v = *reinterpret_cast<const f32x4*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
@@ -343,12 +346,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-      const int p = tid + i * 256;
+      const int p = tid + i * NT;
       if (p < np_p) put(sPh, sPl, (p / PPIECES) * PROW + (p % PPIECES) * 8, pre_p[i]);
     }
 #pragma unroll
     for (int i = 0; i < NPQ; ++i) {
-      const int p = tid + i * 256;
+      const int p = tid + i * NT;
       if (p < np_q) put(sQh, sQl, (p / QPIECES) * QROW + (p % QPIECES) * 8, pre_q[i]);
     }
     __syncthreads();
@@ -493,7 +496,7 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
 
 struct WgPlan { int MI, nbf, items, a_tiles, b_tiles, nsplit, tiles_per_split; size_t ws_bytes; };
 
-static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const WgradArgs& g) {
+static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const WgradArgs& g, int blocks = 1024) {
   WgPlan p;
   const int CaPad = round_up(Ca, 16), CbPad = round_up(Cb, 16);
   p.MI = CaPad >= 64 ? 4 : 2;
@@ -504,7 +507,8 @@ static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const Wg
   const int ntiles = B * g.tiles_x * g.tiles_y;
   const size_t slab1 = (size_t)g.ntaps * CaPad * CbPad * sizeof(float);
   // ~4 blocks per CU: with the 64-pixel fp32 tiles two blocks share a CU, one loading while the other multiplies
-  int ns = std::max(1, 1024 / (p.a_tiles * p.b_tiles));
+  // (split-bf16 arithmetic: the MFMAs are 5x cheaper, the slab traffic is not -- fewer, longer splits, `blocks` in total)
+  int ns = std::max(1, blocks / (p.a_tiles * p.b_tiles));
   ns = std::min(ns, ntiles);
   ns = std::min<int>(ns, std::max<size_t>(1, ((size_t)32 << 20) / slab1));
   p.tiles_per_split = cdiv(ntiles, ns);
@@ -567,7 +571,7 @@ static int wgrad_items(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
   return SX_ERR_UNSUPPORTED;
 }
 
-template <int MI, int ITEMS>
+template <int MI, int ITEMS, int NW = 4>
 static int launch_wgrad_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
   constexpr int PROW = MI * 16 * 2 + 16, QROW = 64 * 2 + 16;
   const size_t smem = 2 * ((size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW);
@@ -576,10 +580,10 @@ static int launch_wgrad_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) 
     set_error("wgrad: fp32 tile of %d + %d pixels exceeds the prefetch slots", a.TP, a.LH * a.LW);
     return SX_ERR_UNSUPPORTED;
   }
-  auto kern = wgrad_x3_kernel<MI, ITEMS>;
+  auto kern = wgrad_x3_kernel<MI, ITEMS, NW>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(wgrad_x3)"));
-  hipLaunchKernelGGL(kern, dim3(p.a_tiles, p.b_tiles, p.nsplit), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(p.a_tiles, p.b_tiles, p.nsplit), dim3(NW * 64), smem, st, a);
   SX_LAUNCH_CHECK("wgrad_x3");
   return SX_OK;
 }
@@ -592,7 +596,9 @@ static int wgrad_items_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
     case 3: return launch_wgrad_x3<MI, 3>(a, p, st);
     case 4: return launch_wgrad_x3<MI, 4>(a, p, st);
     case 5: return launch_wgrad_x3<MI, 5>(a, p, st);
-    case 9: return launch_wgrad_x3<MI, 9>(a, p, st);
+    case 9:
+      if constexpr (MI == 4) return launch_wgrad_x3<MI, 5, 8>(a, p, st);      // 36 items on eight waves
+      else return launch_wgrad_x3<MI, 9>(a, p, st);
   }
   set_error("wgrad: unexpected item count %d", p.items);
   return SX_ERR_UNSUPPORTED;
@@ -641,7 +647,8 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
       }
     }
   }
-  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a);
+  static const int x3_blocks = env_int("SX_X3_WG_BLOCKS", 512);
+  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && fp32_split()) ? x3_blocks : 1024);
   SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
              (long long)slab_bytes, p.ws_bytes);
   a.P = P; a.Q = Q; a.slab = (float*)slab;

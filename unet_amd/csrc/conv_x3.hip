@@ -28,13 +28,17 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
   }
 }
 
-// NPX: pixel pieces (16 bytes = 4 fp32 channels) a thread stages per chunk
-template <int MI, int NI, int WM, int WN, int NPX>
-__global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a) {
+// One block = WM x WN waves, a tile of WM*MI*16 output channels x WN*NI*16 pixels.  Blocks are persistent: a block walks
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the (tile, K chunk) pairs form ONE sequence of stages, so the register
+// prefetch of the next stage also runs across tile boundaries and under the epilogue; with a single K chunk the weight
+// image stays in LDS for every tile of the block.  Fragments of tap t+1 are read while the MFMAs of tap t run.
+// NPX: pixel pieces (16 bytes = 4 fp32 channels) a thread stages per chunk.
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS != 4) ? 2 : 1) void conv_x3_kernel(ConvArgs a) {     // <= 32-channel tiles: two blocks per CU
+  constexpr int NT = WM * WN * 64;
   constexpr int BMC = WM * MI * 16;
-  constexpr int NPW = (9 * BMC * 8 + 255) / 256;        // weight pieces per thread (nine taps at most)
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(WN * NI * 16 == 128, "128-pixel tile");
+  constexpr int TAPW = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
+  constexpr int NPW = (TAPS * BMC * 8 + NT - 1) / NT;       // weight pieces per thread
   extern __shared__ __align__(16) char smem[];
   char* sm_pix = smem;
   char* sm_w = smem + a.LH * a.LW * ROW3;
@@ -42,13 +46,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int n = lane & 15, g = lane >> 4;
-
-  int bid = blockIdx.x;
-  const int tx_i = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty_i = bid % a.tiles_y; bid /= a.tiles_y;
-  const int b = bid;
-  const int ty0 = ty_i * a.TH, tx0 = tx_i * a.TW;
   const int cb = blockIdx.y * BMC;
+  const int ntiles = a.B * a.tiles_y * a.tiles_x;
 
   int pix_off[NI];
 #pragma unroll
@@ -61,203 +60,272 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < MI; ++j) w_off[j] = ((wm * MI + j) * 16 + n) * ROW3 + g * 16;
 
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int j = 0; j < MI; ++j)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const float* __restrict__ xb = reinterpret_cast<const float*>(a.x) + (int64_t)b * a.Hx * a.Wx * a.x_ld;   // this sample
+  const float* __restrict__ xg = reinterpret_cast<const float*>(a.x);
   const char* __restrict__ wg = reinterpret_cast<const char*>(a.w);
+  float* __restrict__ yg = reinterpret_cast<float*>(a.y);
   const int npix_pieces = a.LH * a.LW * 8;
-  const int nw_pieces = a.ntaps * BMC * 8;
-  const int iy0 = ty0 * a.in_scale - a.pad, ix0 = tx0 * a.in_scale - a.pad;
+  constexpr int nw_pieces = TAPS * BMC * 8;
   const int kch = a.KPad >> 5;
+  const bool do_stats = a.gn_stats != nullptr;
+  float* sm_stat = reinterpret_cast<float*>(smem);   // [WN][BMC][2], overlays the pixel image between two tiles
 
-  // the next chunk's pieces are fetched into registers under this chunk's MFMAs; coordinates are decoded once
+  // staging slots: halo coordinates of this thread's pixel pieces and byte offsets of its weight pieces, decoded once
   f32x4 pre_x[NPX];
   u32x4 pre_w[NPW];
-  int px_off[NPX];          // element offset inside the sample without the chunk term; < 0 = reads as zero
-  int64_t pw_off[NPW];      // byte offset without the chunk term; < 0 = reads as zero
+  int sl_y[NPX], sl_x[NPX];
+  int pw_off[NPW];          // byte offset without the chunk term (a packed weight is a few MB); < 0 = reads as zero
 #pragma unroll
   for (int i = 0; i < NPX; ++i) {
-    const int p = tid + i * 256, r = p >> 3, q = p & 7;
-    const int ly = r / a.LW, lx = r - ly * a.LW;
-    const int iy = iy0 + ly, ix = ix0 + lx;
-    const bool ok = p < npix_pieces && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
-    px_off[i] = ok ? (iy * a.Wx + ix) * a.x_ld + q * 4 : -1;
+    const int p = tid + i * NT, r = p >> 3;
+    const int ly = r / a.LW;
+    sl_y[i] = p < npix_pieces ? ly : (1 << 28);       // pieces past the image fail every bounds test
+    sl_x[i] = r - ly * a.LW;
   }
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int p = tid + i * 256, r = p >> 3, q = p & 7;
+    const int p = tid + i * NT, r = p >> 3, q = p & 7;
     const int tap = r / BMC, row = r - tap * BMC;
     const bool ok = p < nw_pieces && cb + row < a.RTot;
-    pw_off[i] = ok ? (((int64_t)tap * a.RTot + cb + row) * kch << 7) + q * 16 : -1;
+    pw_off[i] = ok ? (((tap * a.RTot + cb + row) * kch) << 7) + q * 16 : -1;
   }
-  auto fetch = [&](int kc) {      // kc = first channel of the chunk
+  struct Tile { int b, ty0, tx0; };
+  auto tile_at = [&](int t) {
+    Tile T;
+    T.tx0 = (t % a.tiles_x) * a.TW; t /= a.tiles_x;
+    T.ty0 = (t % a.tiles_y) * a.TH; T.b = t / a.tiles_y;
+    return T;
+  };
+  auto fetch = [&](const Tile& T, int kc, bool weights) {      // kc = first channel of the chunk
+    const float* xb = xg + (int64_t)T.b * a.Hx * a.Wx * a.x_ld;
+    const int iy0 = T.ty0 * a.in_scale - a.pad, ix0 = T.tx0 * a.in_scale - a.pad;
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
+      const int iy = iy0 + sl_y[i], ix = ix0 + sl_x[i];
+      const int c = kc + ((tid + i * NT) & 7) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (px_off[i] >= 0 && kc + ((tid + i * 256) & 7) * 4 < a.K) v = *reinterpret_cast<const f32x4*>(xb + px_off[i] + kc);
+      if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.K) v = *reinterpret_cast<const f32x4*>(xb + (iy * a.Wx + ix) * a.x_ld + c);
       pre_x[i] = v;
     }
+    if (weights) {
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + pw_off[i] + ((int64_t)(kc >> 5) << 7));
-      pre_w[i] = v;
+      for (int i = 0; i < NPW; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + (pw_off[i] + ((kc >> 5) << 7)));
+        pre_w[i] = v;
+      }
     }
   };
-  fetch(0);
-  for (int kc = 0; kc < a.KPad; kc += 32) {
-    __syncthreads();
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  Tile cur = tile_at(t);
+  fetch(cur, 0, true);
+  bool w_in_regs = true;
+  while (t < ntiles) {
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int p = tid + i * 256;
-      if (p < npix_pieces) {
-        bf16x4 hi, lo;
-        split4(pre_x[i], hi, lo);
-        char* dst = sm_pix + (p >> 3) * ROW3 + (p & 7) * 8;
-        *reinterpret_cast<bf16x4*>(dst) = hi;
-        *reinterpret_cast<bf16x4*>(dst + LOFF) = lo;
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tn = t + (int)gridDim.x;
+    const Tile nxt = tile_at(tn < ntiles ? tn : t);
+
+    for (int kc = 0; kc < a.KPad; kc += 32) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int p = tid + i * NT;
+        if (p < npix_pieces) {
+          bf16x4 hi, lo;
+          split4(pre_x[i], hi, lo);
+          char* dst = sm_pix + (p >> 3) * ROW3 + (p & 7) * 8;
+          *reinterpret_cast<bf16x4*>(dst) = hi;
+          *reinterpret_cast<bf16x4*>(dst + LOFF) = lo;
+        }
+      }
+      if (w_in_regs) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          const int p = tid + i * NT;
+          if (p < nw_pieces) *reinterpret_cast<u32x4*>(sm_w + (p >> 3) * ROW3 + (p & 7) * 16) = pre_w[i];
+        }
+      }
+      __syncthreads();
+      // next stage: the next chunk of this tile, or the first chunk of the block's next tile
+      if (kc + 32 < a.KPad) fetch(cur, kc + 32, true);
+      else if (tn < ntiles) { w_in_regs = kch > 1; fetch(nxt, 0, w_in_regs); }
+
+      // one wave per SIMD: the fragments of tap t+1 are read while the MFMAs of tap t run (two register sets); with two
+      // waves per SIMD the other wave covers the LDS latency and one set keeps the kernel inside 256 VGPRs
+      constexpr int NS = NT == 256 ? 2 : 1;
+      bf16x8 Ah[NS][MI], Al[NS][MI], Bh[NS][NI], Bl[NS][NI];
+      auto read_tap = [&](int tap, int slot) {
+        const int tyy = tap / TAPW, txx = tap - tyy * TAPW;
+        const int toff = (tyy * a.LW + txx) * ROW3;
+        const char* wt = sm_w + tap * BMC * ROW3;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          Ah[slot][j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j]);
+          Al[slot][j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j] + LOFF);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          Bh[slot][i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff);
+          Bl[slot][i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + LOFF);
+        }
+      };
+      if constexpr (NS == 2) read_tap(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int sl = NS == 2 ? (tap & 1) : 0;
+        if constexpr (NS == 2) {
+          if (tap + 1 < TAPS) read_tap(tap + 1, sl ^ 1);
+          __builtin_amdgcn_sched_barrier(0);         // keep the reads of the next tap above this tap's MFMAs
+        } else {
+          read_tap(tap, 0);
+        }
+        // the two small terms first, the leading term last
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[sl][j], Bh[sl][i], acc[j][i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[sl][j], Bl[sl][i], acc[j][i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[sl][j], Bh[sl][i], acc[j][i], 0, 0, 0);
+        if constexpr (NS == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
+
+    // ---------------------------------------------------------------- epilogue of tile `cur` (as conv_igemm_kernel<float>)
+    if (do_stats) __syncthreads();        // every wave is done with the pixel image: sm_stat may overlay it
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int p = tid + i * 256;
-      if (p < nw_pieces) *reinterpret_cast<u32x4*>(sm_w + (p >> 3) * ROW3 + (p & 7) * 16) = pre_w[i];
-    }
-    __syncthreads();
-    if (kc + 32 < a.KPad) fetch(kc + 32);
-    for (int tap = 0; tap < a.ntaps; ++tap) {
-      const int tyy = tap / a.tapw, txx = tap - tyy * a.tapw;
-      const int toff = (tyy * a.LW + txx) * ROW3;
-      const char* wt = sm_w + tap * BMC * ROW3;
-      bf16x8 Ah[MI], Al[MI], Bh[NI], Bl[NI];
-#pragma unroll
-      for (int j = 0; j < MI; ++j) {
-        Ah[j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j]);
-        Al[j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j] + LOFF);
-      }
+    for (int j = 0; j < MI; ++j) {
+      const int cl = (wm * MI + j) * 16 + 4 * g;
+      const int c0 = cb + cl;
+      int co = c0, tap = 0;
+      if (a.shuffle) { tap = c0 / a.RPad; co = c0 - tap * a.RPad; }
+      const bool cvalid = (c0 < a.RTot) && (co < a.R);
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias && cvalid) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        Bh[i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff);
-        Bl[i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + LOFF);
+        const int m = (wn * NI + i) * 16 + n;
+        const int py = m >> a.tw_log2, px = m & (a.TW - 1);
+        int oy = cur.ty0 + py, ox = cur.tx0 + px;
+        const bool pvalid = (oy < a.H) && (ox < a.W);
+        if (a.shuffle) { oy = 2 * oy + (tap >> 1); ox = 2 * ox + (tap & 1); }
+        f32x4 v = acc[j][i] + bias;
+        if (pvalid && cvalid) {
+          float* dst = yg + ((int64_t)(cur.b * a.Hy + oy) * a.Wy + ox) * a.y_ld + co;
+          if (a.accumulate) v += load4(dst);
+          store4(dst, v);
+          if (do_stats) { s1 += v; s2 += v * v; }
+        }
       }
-      // the two small terms first, the leading term last
+      if (do_stats) {
 #pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh[i], acc[j][i], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl[i], acc[j][i], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh[i], acc[j][i], 0, 0, 0);
-    }
-  }
-
-  // ------------------------------------------------------------------ epilogue (as conv_igemm_kernel<float>)
-  float* __restrict__ yg = reinterpret_cast<float*>(a.y);
-  const bool do_stats = a.gn_stats != nullptr;
-  float* sm_stat = reinterpret_cast<float*>(smem);   // [WN][BMC][2], reused after the K loop
-  if (do_stats) __syncthreads();
-
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int cl = (wm * MI + j) * 16 + 4 * g;
-    const int c0 = cb + cl;
-    int co = c0, tap = 0;
-    if (a.shuffle) { tap = c0 / a.RPad; co = c0 - tap * a.RPad; }
-    const bool cvalid = (c0 < a.RTot) && (co < a.R);
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias && cvalid) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int m = (wn * NI + i) * 16 + n;
-      const int py = m >> a.tw_log2, px = m & (a.TW - 1);
-      int oy = ty0 + py, ox = tx0 + px;
-      const bool pvalid = (oy < a.H) && (ox < a.W);
-      if (a.shuffle) { oy = 2 * oy + (tap >> 1); ox = 2 * ox + (tap & 1); }
-      f32x4 v = acc[j][i] + bias;
-      if (pvalid && cvalid) {
-        float* dst = yg + ((int64_t)(b * a.Hy + oy) * a.Wy + ox) * a.y_ld + co;
-        if (a.accumulate) v += load4(dst);
-        store4(dst, v);
-        if (do_stats) { s1 += v; s2 += v * v; }
-      }
-    }
-    if (do_stats) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t1 = sum16(s1[r]), t2 = sum16(s2[r]);
-        if (n == 0) {
-          sm_stat[(wn * BMC + cl + r) * 2 + 0] = t1;
-          sm_stat[(wn * BMC + cl + r) * 2 + 1] = t2;
+        for (int r = 0; r < 4; ++r) {
+          const float t1 = sum16(s1[r]), t2 = sum16(s2[r]);
+          if (n == 0) {
+            sm_stat[(wn * BMC + cl + r) * 2 + 0] = t1;
+            sm_stat[(wn * BMC + cl + r) * 2 + 1] = t2;
+          }
         }
       }
     }
-  }
-  if (do_stats) {
-    __syncthreads();
-    if (tid < BMC) {
-      const int c = cb + tid;
-      const int cend = min(a.R, cb + BMC);
-      if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
-        const int grp = c / a.cpg;
-        float t1 = 0.f, t2 = 0.f;
-        for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
+    if (do_stats) {
+      __syncthreads();
+      if (tid < BMC) {
+        const int c = cb + tid;
+        const int cend = min(a.R, cb + BMC);
+        if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
+          const int grp = c / a.cpg;
+          float t1 = 0.f, t2 = 0.f;
+          for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
 #pragma unroll
-          for (int w = 0; w < WN; ++w) {
-            t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
-            t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
-          }
-        const int G = a.R / a.cpg;
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
+            for (int w = 0; w < WN; ++w) {
+              t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
+              t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
+            }
+          const int G = a.R / a.cpg;
+          atomicAdd(a.gn_stats + ((int64_t)cur.b * G + grp) * 2 + 0, t1);
+          atomicAdd(a.gn_stats + ((int64_t)cur.b * G + grp) * 2 + 1, t2);
+        }
       }
+      // (the next stage starts with a barrier: the image is not rewritten before these reads are done)
     }
+    t = tn;
+    cur = nxt;
   }
 }
 
-template <int MI, int NI, int WM, int WN, int NPX>
-static int launch_x3(const ConvArgs& a, hipStream_t st) {
-  constexpr int BMC = WM * MI * 16;
-  size_t smem = (size_t)(a.LH * a.LW + a.ntaps * BMC) * ROW3;
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX>
+static int launch_x3(ConvArgs a, hipStream_t st) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BMC = WM * MI * 16, TP = WN * NI * 16;
+  const int taph = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
+  a.TH = TP / a.TW;
+  a.LH = (a.TH - 1) * a.in_scale + taph;
+  a.tiles_y = cdiv(a.H, a.TH);
+  size_t smem = (size_t)(a.LH * a.LW + TAPS * BMC) * ROW3;
   const size_t stat_bytes = (size_t)WN * BMC * 2 * sizeof(float);
   if (smem < stat_bytes) smem = stat_bytes;
   if (smem > 160 * 1024) { set_error("conv tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
-  if (a.LH * a.LW * 8 > NPX * 256 || a.ntaps > 9) {
-    set_error("conv: fp32 tile of %d pixels x %d taps exceeds the prefetch slots", a.LH * a.LW, a.ntaps);
+  if (a.LH * a.LW * 8 > NPX * NT) {
+    set_error("conv: fp32 tile of %d pixels exceeds the prefetch slots", a.LH * a.LW);
     return SX_ERR_UNSUPPORTED;
   }
   if ((int64_t)a.Hx * a.Wx * a.x_ld >= ((int64_t)1 << 31)) { set_error("conv: one sample exceeds 2^31 elements"); return SX_ERR_UNSUPPORTED; }
-  auto kern = conv_x3_kernel<MI, NI, WM, WN, NPX>;
+  auto kern = conv_x3_kernel<TAPS, MI, NI, WM, WN, NPX>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_x3)"));
-  dim3 grid(a.tiles_x * a.tiles_y * a.B, cdiv(a.RTot, BMC));
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  // persistent grid: as many blocks as the LDS images allow on 256 CUs (2 in flight per CU at least when they are small)
+  const int ntiles = a.tiles_x * a.tiles_y * a.B;
+  const int gy = cdiv(a.RTot, BMC);
+  // resident blocks per CU as the runtime computes it from registers and LDS (cached per 4 KB bucket of LDS: the query is a host call)
+  static std::atomic<int> occ[41];
+  int per_cu = occ[smem >> 12].load(std::memory_order_relaxed);
+  if (per_cu == 0) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NT, smem);
+    if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(conv_x3)");
+    per_cu = std::max(1, std::min(4, nb));
+    occ[smem >> 12].store(per_cu, std::memory_order_relaxed);
+  }
+  static const int oversub = env_int("SX_X3_WAVES", 1);         // tuning knob: tiles per resident block slot
+  int gx = std::max(1, std::min(ntiles, (256 * per_cu * oversub) / gy));
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NT), smem, st, a);
   SX_LAUNCH_CHECK("conv_x3");
   return SX_OK;
 }
 
-template <int NPX>
+template <int TAPS, int NPX>
 static int x3_tiles(const ConvArgs& a, hipStream_t st) {
-  if (a.RTot <= 16) return launch_x3<1, 2, 1, 4, NPX>(a, st);
-  if (a.RTot <= 32) return launch_x3<2, 2, 1, 4, NPX>(a, st);
-  return launch_x3<2, 4, 2, 2, NPX>(a, st);
+  if (a.RTot <= 16) return launch_x3<TAPS, 1, 2, 1, 4, NPX>(a, st);
+  if (a.RTot <= 32) return launch_x3<TAPS, 2, 2, 1, 4, NPX>(a, st);
+  // 64 channels x 256 pixels on 8 waves where a sample has that many pixels in tiles of this width (half the weight
+  // traffic per pixel: at one block per CU the 128-pixel form was bound by re-fetching 74 KB of weights per chunk)
+  if constexpr (TAPS != 4) {
+    constexpr int NPX8 = TAPS == 9 ? 6 : 4;
+    const int th = 256 / a.TW;
+    if (a.H * a.TW >= 256 && (th + (TAPS == 9 ? 2 : 0)) * a.LW * 8 <= NPX8 * 512) return launch_x3<TAPS, 2, 4, 2, 4, NPX8>(a, st);
+  }
+  return launch_x3<TAPS, 2, 4, 2, 2, NPX>(a, st);
 }
 
 int conv_x3_dispatch(const ConvArgs& a, hipStream_t st) {
   if (a.KPad % 32) { set_error("conv_x3: packed K %d is not a multiple of 32", a.KPad); return SX_ERR_INVALID; }
-  // the transposed convolution's data gradient gathers from a 16 x 32 pixel image (16 pieces per thread), everything
-  // else from at most 34 x 6 pixels (7)
-  if (a.in_scale == 2) return x3_tiles<16>(a, st);
-  return x3_tiles<7>(a, st);
+  // pieces per thread at 256 threads: the transposed convolution's data gradient gathers from a 16 x 32 pixel image (16),
+  // everything else from at most 34 x 6 pixels (7)
+  if (a.ntaps == 9) return x3_tiles<9, 7>(a, st);
+  if (a.ntaps == 4) return x3_tiles<4, 16>(a, st);
+  return x3_tiles<1, 7>(a, st);
 }
 
 }  // namespace sx
