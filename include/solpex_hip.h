@@ -75,7 +75,7 @@ int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k);
  *     relative L2 on a whole convolution (TF32, cuDNN's default for the reference's fp32 convolutions, carries 4.9e-4),
  *     at 3/16 of the matrix-core time of exact fp32;
  *   exact: v_mfma_f32_16x16x4_f32 throughout (environment SX_FP32_EXACT=1 at start-up, or this call).
- * Returns the previous setting (1 = exact).  Packed fp32 weights are specific to the mode they were packed in: repack
+ * Returns the previous setting (1 = exact); on < 0 only queries.  Packed fp32 weights are specific to the mode they were packed in: repack
  * after a switch.  Process-wide; do not switch while calls are in flight on other threads.  No counterpart in the
  * reference (torch.backends.cudnn.allow_tf32 is the closest knob). */
 int sx_set_fp32_exact(int on);

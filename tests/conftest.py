@@ -21,3 +21,14 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(params=["split", "exact"])
+def fp32_mode(request):
+    """fp32 arithmetic of the convolution kernels for one test: "split" = the default (bf16 hi + lo planes, three bf16 MFMAs
+    per product block, unet_amd/csrc/conv_x3.hip), "exact" = fp32 MFMA (sx_set_fp32_exact(1)).  Restored afterwards."""
+    from unet_amd import _lib
+    lib = _lib.lib()
+    was = lib.sx_set_fp32_exact(1 if request.param == "exact" else 0)
+    yield request.param
+    lib.sx_set_fp32_exact(was)

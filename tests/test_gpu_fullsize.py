@@ -52,7 +52,7 @@ def cfg2_case():
 
 
 @pytest.mark.parametrize("dtype,tol_loss,tol_g,cos_min", [(torch.float32, 1e-4, 5e-4, 0.999999), (torch.bfloat16, 1e-2, 6e-2, 0.998)])
-def test_cfg2_train_step_against_oracle(cfg2_case, dtype, tol_loss, tol_g, cos_min):
+def test_cfg2_train_step_against_oracle(cfg2_case, dtype, tol_loss, tol_g, cos_min, fp32_mode):
     """TrainEngine.train_step at batch 64, 128x64, cfg A: loss, mae_norm, every parameter gradient, the gradient norm the
     clip uses, and the parameters after clip + AdamW, against one oracle step."""
     from unet_amd.models import UNet
@@ -90,7 +90,7 @@ def test_cfg2_train_step_against_oracle(cfg2_case, dtype, tol_loss, tol_g, cos_m
     assert upd_err < (5e-3 if dtype == torch.float32 else 0.15), upd_err
     for k, q in model.named_parameters():
         assert rel_err(q.detach().cpu(), p_ref[k]) < (1e-3 if dtype == torch.float32 else 2e-2), k
-    print(f"[cfg2 {dtype}] loss {loss:.6f} vs {loss_ref_v:.6f}; worst gradient {worst}; update vector error {upd_err:.3e}")
+    print(f"[cfg2 {dtype} {fp32_mode}] loss {loss:.6f} vs {loss_ref_v:.6f}; worst gradient {worst}; update vector error {upd_err:.3e}")
 
 
 def test_cfg2_forward_eval_after_train_step_uses_updated_weights(cfg2_case):

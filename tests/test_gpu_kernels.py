@@ -23,6 +23,16 @@ def L():
     return _lib
 
 
+@pytest.fixture(scope="module", autouse=True, params=["split", "exact"])
+def fp32_mode(request, L):
+    """Every kernel test runs in both fp32 arithmetic modes: split-bf16 (the default: three bf16 MFMAs per product block,
+    conv_x3.hip) and exact fp32 MFMA (sx_set_fp32_exact(1)); packed fp32 weights are made after the switch.  The bf16
+    cases do not depend on it."""
+    was = L.lib().sx_set_fp32_exact(1 if request.param == "exact" else 0)
+    yield request.param
+    assert L.lib().sx_set_fp32_exact(was) == (1 if request.param == "exact" else 0)
+
+
 def dev(x, dt=None):
     x = x.cuda()
     return x if dt is None else x.to(dt)
@@ -590,3 +600,34 @@ def test_adamw_clip_matches_golden(L, golden):
         for i in range(n):
             assert max_err(flat_p[off:off + sizes[i]].cpu(), g[f"p{step + 1}_{i}"].reshape(-1)) < 2e-6
             off += sizes[i]
+
+
+def test_fp32_split_arithmetic_error_against_fp64(L, fp32_mode):
+    """What the split-bf16 mode costs in accuracy, measured against fp64 on one 3x3 convolution and its weight gradient
+    (256 -> 256 channels, 16x8): <= 2e-5 relative L2 (three bf16 products of hi/lo planes, fp32 accumulation; bound per
+    product 3 * 2^-18), exact mode <= 2e-6.  TF32, cuDNN's default for the reference's fp32 convolutions, sits at ~5e-4."""
+    B, H, W, Cc = 4, 16, 8, 256
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)
+    dy = torch.randn(B, Cc, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    xd, dyd = nhwc(x, 0), nhwc(dy, 0)
+    y = torch.empty(B, H, W, Cc, dtype=torch.float32, device="cuda")
+    wp = pack(L, 0, L.SX_CONV3, 0, w, Cc, Cc, Cc, Cc)
+    L.check(L.lib().sx_conv_forward(0, L.SX_CONV3, B, H, W, Cc, Cc, L.ptr(xd), Cc, H, W, L.ptr(wp), None, L.ptr(y), Cc, H, W, 0,
+                                    None, 0, L.stream_ptr()))
+    nb = L.lib().sx_conv_wgrad_workspace_bytes(L.SX_CONV3, B, H, W, Cc, Cc)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    dw = torch.empty(Cc, Cc, 3, 3, dtype=torch.float32, device="cuda")
+    L.check(L.lib().sx_conv_wgrad(0, L.SX_CONV3, B, H, W, Cc, Cc, Cc, Cc, L.ptr(dyd), Cc, L.ptr(xd), Cc, H, W, L.ptr(dw), 0,
+                                  L.ptr(ws), nb, L.stream_ptr()))
+    torch.cuda.synchronize()
+    e_y = float((from_nhwc(y, Cc).double() - ref).norm() / ref.norm())
+    e_w = float((dw.cpu().double() - wref).norm() / wref.norm())
+    print(f"[fp32 {fp32_mode}] conv {e_y:.2e}  wgrad {e_w:.2e}")
+    bound = 2e-6 if fp32_mode == "exact" else 2e-5
+    assert e_y < bound and e_w < bound
+    if fp32_mode == "split":
+        assert e_y > 5e-7          # the split kernels really ran (the exact ones sit at ~2e-7)

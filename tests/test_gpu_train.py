@@ -133,8 +133,9 @@ def test_train_unet_bf16_loop_tracks_the_reference_history(golden, tmp_path):
         assert rel_err(fin[k].cpu(), g["final::" + k]) < 3e-2, k
 
 
-def test_engine_step_equals_autograd_path_and_oracle_adamw():
-    """TrainEngine.train_step (direct C calls, flat arenas) == autograd path + oracle AdamW/clip on the same batch."""
+def test_engine_step_equals_autograd_path_and_oracle_adamw(fp32_mode):
+    """TrainEngine.train_step (direct C calls, flat arenas) == autograd path + oracle AdamW/clip on the same batch, in both
+    fp32 arithmetic modes."""
     from oracle import optim_ref
     from oracle.unet_ref import UNetCfg, init_state_dict
     from unet_amd.models import UNet
@@ -167,8 +168,9 @@ def test_engine_step_equals_autograd_path_and_oracle_adamw():
     for k, g in zip(names, clipped):
         pn, _, _ = optim_ref.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-2, weight_decay=1e-4)
         # step-1 Adam moves every weight by ~lr*sign(g): a gradient element within the run-to-run atomic-order noise
-        # of zero may flip, which costs ~1e-5 of the tensor norm per flipped element
-        assert rel_err(pb[k].detach().cpu(), pn) < 1e-4, k
+        # of zero may flip, which costs ~1e-5 of the tensor norm per flipped element.  The split-bf16 arithmetic carries
+        # ~4e-6 per convolution instead of ~2e-7, so more of the near-zero elements flip there: 3e-4 (measured 1.1e-4)
+        assert rel_err(pb[k].detach().cpu(), pn) < (1e-4 if fp32_mode == "exact" else 3e-4), k
 
 
 def test_load_checkpoint_depth3_round_trip(tmp_path):
@@ -198,9 +200,11 @@ def test_load_checkpoint_depth3_round_trip(tmp_path):
         predict_fields(m2, norm2, tr["mask"][0, 0].numpy(), tr["params"][0].numpy(), Rn=np.zeros((3, 3)), Zn=np.zeros((3, 3)))
 
 
-def test_engine_dp_code_path_single_process_equals_plain_step():
+def test_engine_dp_code_path_single_process_equals_plain_step(fp32_mode):
     """world > 1 makes the engine split the encoder half's backward (SX_BWD_ONLY_BOTTLENECK / SX_BWD_AFTER_BOTTLENECK) and
-    issue its collectives; with no process group they are no-ops, so the gradients must equal the one-call path's."""
+    issue its collectives; with no process group they are no-ops, so the gradients must equal the one-call path's up to the
+    run-to-run noise of the fp32 atomics in the GroupNorm statistics (~1e-7 per value; the split-bf16 arithmetic re-rounds
+    activations to hi + lo planes, where a last-bit difference can move a lo value by one bf16 step: ~1e-6 per value)."""
     from oracle.unet_ref import UNetCfg, init_state_dict
     from unet_amd.models import UNet
     from unet_amd.train import TrainEngine
@@ -219,7 +223,7 @@ def test_engine_dp_code_path_single_process_equals_plain_step():
         torch.cuda.synchronize()
         grads.append({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
     for k in grads[0]:
-        assert rel_err(grads[1][k], grads[0][k]) < 1e-5, k
+        assert rel_err(grads[1][k], grads[0][k]) < (1e-5 if fp32_mode == "exact" else 5e-5), k
 
 
 @pytest.mark.parametrize("dtype", [0, 1])

@@ -42,7 +42,7 @@ def run_case(g, dtype):
 
 
 @pytest.mark.parametrize("name", ["unet_small.npz", "unet_odd.npz", "unet_d3_ms.npz"])
-def test_unet_fp32_matches_reference_vectors(golden, name):
+def test_unet_fp32_matches_reference_vectors(golden, name, fp32_mode):
     g = golden(name)
     model, pred, b, loss, params = run_case(g, torch.float32)
     assert pred.dtype == torch.float32
@@ -77,7 +77,7 @@ def test_unet_bf16_within_tolerance(golden, name):
         assert rel_err(params.grad.cpu(), g["dparams"]) < 6e-2
 
 
-def test_unet_cfgA_full_size_summary(golden):
+def test_unet_cfgA_full_size_summary(golden, fp32_mode):
     """cfg A (base 32, depth 3, 128x64): prediction, loss and per-tensor gradient norms of the reference."""
     g = golden("unet_cfgA_summary.npz")
     model, pred, b, loss, params = run_case(g, torch.float32)

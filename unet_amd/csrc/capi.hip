@@ -49,7 +49,7 @@ int fp32_split() {
 
 extern "C" int sx_set_fp32_exact(int on) {
   const int was = sx::fp32_split() ? 0 : 1;
-  sx::g_fp32_split.store(on ? 0 : 1, std::memory_order_relaxed);
+  if (on >= 0) sx::g_fp32_split.store(on ? 0 : 1, std::memory_order_relaxed);      // on < 0: query only
   return was;
 }
 extern "C" int sx_version(void) { return SX_VERSION; }

@@ -281,7 +281,8 @@ class UNet(nn.Module):
         # Packed (MFMA-layout) weights are cached per dtype/device and rebuilt when a parameter's
         # storage or version counter changed; in training mode they are rebuilt every forward.
         # `_wgen` counts updates made through raw pointers (TrainEngine's AdamW kernel), which bump no version counter.
-        key = (self._wgen,) + tuple((p.data_ptr(), p._version) for p in params)
+        # fp32 packs also depend on the arithmetic mode they were made in (split-bf16 / exact, sx_set_fp32_exact).
+        key = (self._wgen, L.lib().sx_set_fp32_exact(-1)) + tuple((p.data_ptr(), p._version) for p in params)
         ckey = (dtype, str(device))
         ent = self._wcache.get(ckey)
         sess = UNetSession(self._cfg, B, H, W, dtype, use_film, device, wpack=None if ent is None else ent[1])
