@@ -80,7 +80,8 @@ template <> struct Mma<float> {
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
 enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3, WS_GATHER = 4 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
-int conv_x3_dispatch(const ConvArgs& a, hipStream_t st);      // fp32 tensors, split-bf16 arithmetic (conv_x3.hip)
+// fp32 tensors, split-bf16 arithmetic (conv_x3.hip); var = WS_PLAIN or WS_CENTER; 1 = variant / shape not covered
+int conv_x3_dispatch(const ConvArgs& a, hipStream_t st, int var = WS_PLAIN);
 
 // Weight packing for a whole table of layers in one launch (conv_igemm.hip).
 struct PackDesc {

@@ -624,6 +624,30 @@ extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, in
     const int rc = conv_ws_try(a, SX_CONV3, (hipStream_t)stream, WS_CENTER);
     if (rc <= 0) return rc;
   }
+  if (dtype == SX_F32 && fp32_split() && C % 32 == 0 && dyr_ld % 4 == 0 && Cin % 4 == 0 && dx_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
+      ((uintptr_t)dyr % 16) == 0 && ((uintptr_t)packed3_t % 16) == 0 && ((uintptr_t)packed1_t % 16) == 0 && ((uintptr_t)dx % 16) == 0) {
+    // the same joint form in split-bf16 arithmetic: one pass, no read-modify-write of dx
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dyr; a.w = packed3_t; a.y = dx; a.w2 = packed1_t;
+    a.B = B; a.H = H; a.W = W; a.Hx = H; a.Wx = W; a.x_ld = dyr_ld; a.Hy = H; a.Wy = W; a.y_ld = dx_ld;
+    a.K = C; a.KPad = C;
+    a.R = Cin; a.RPad = round_up(Cin, 16); a.RTot = a.RPad;
+    a.ntaps = 9; a.tapw = 3; a.in_scale = 1; a.pad = 1;
+    a.tw_log2 = W > 8 ? 4 : (W > 4 ? 3 : 2);
+    a.TW = 1 << a.tw_log2;
+    a.LW = a.TW + 2;
+    a.tiles_x = cdiv(W, a.TW);
+    const int rc = conv_x3_dispatch(a, (hipStream_t)stream, WS_CENTER);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      if (ch_sum) {
+        SX_REQUIRE(ch_sum_n > 0 && ch_sum_n <= Cin && ch_sum_n % 8 == 0 && dx_ld % 8 == 0, "sx_conv3_shortcut_dgrad: bad channel-sum request");
+        SX_TRY(sx_channel_sum(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, stream));
+      }
+      return SX_OK;
+    }
+  }
   const size_t esz = dtype == SX_BF16 ? 2 : 4;
   SX_TRY(sx_conv_forward(dtype, SX_CONV3, B, H, W, C, Cin, dyr, dyr_ld, H, W, packed3_t, nullptr, dx, dx_ld, H, W, 0, nullptr, 0, stream));
   SX_TRY(sx_conv_forward(dtype, SX_CONV1, B, H, W, C, Cin, (const char*)dyr + (size_t)C * esz, dyr_ld, H, W, packed1_t, nullptr, dx, dx_ld,

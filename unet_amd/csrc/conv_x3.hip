@@ -33,7 +33,7 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 // prefetch of the next stage also runs across tile boundaries and under the epilogue; with a single K chunk the weight
 // image stays in LDS for every tile of the block.  Fragments of tap t+1 are read while the MFMAs of tap t run.
 // NPX: pixel pieces (16 bytes = 4 fp32 channels) a thread stages per chunk.
-template <int TAPS, int MI, int NI, int WM, int WN, int NPX>
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS != 4) ? 2 : 1) void conv_x3_kernel(ConvArgs a) {     // <= 32-channel tiles: two blocks per CU
   constexpr int NT = WM * WN * 64;
   constexpr int BMC = WM * MI * 16;
@@ -66,6 +66,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
   const int npix_pieces = a.LH * a.LW * 8;
   constexpr int nw_pieces = TAPS * BMC * 8;
   const int kch = a.KPad >> 5;
+  // CENTER (the joint data gradient of conv1 + 1x1 shortcut, sx_conv3_shortcut_dgrad): the input holds 2K channels
+  // [dY1 | dR]; chunks of the second half only feed the centre tap, with the 1x1 weights w2 staged in the image of tap 0
+  const int kend = CENTER ? 2 * a.KPad : a.KPad;
+  const char* __restrict__ wg2 = reinterpret_cast<const char*>(a.w2);
   const bool do_stats = a.gn_stats != nullptr;
   float* sm_stat = reinterpret_cast<float*>(smem);   // [WN][BMC][2], overlays the pixel image between two tiles
 
@@ -103,15 +107,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
       const int iy = iy0 + sl_y[i], ix = ix0 + sl_x[i];
       const int c = kc + ((tid + i * NT) & 7) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < a.K) v = *reinterpret_cast<const f32x4*>(xb + (iy * a.Wx + ix) * a.x_ld + c);
+      if (iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx && c < (CENTER ? 2 * a.K : a.K)) v = *reinterpret_cast<const f32x4*>(xb + (iy * a.Wx + ix) * a.x_ld + c);
       pre_x[i] = v;
     }
     if (weights) {
+      if (CENTER && kc >= a.KPad) {
+        // 1x1 weights [row][chunk]: the pieces of tap 0 (p < BMC * 8) take the same rows of w2
 #pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + (pw_off[i] + ((kc >> 5) << 7)));
-        pre_w[i] = v;
+        for (int i = 0; i < NPW; ++i) {
+          const int p = tid + i * NT;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (p < BMC * 8 && pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg2 + (pw_off[i] + (((kc - a.KPad) >> 5) << 7)));
+          pre_w[i] = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + (pw_off[i] + ((kc >> 5) << 7)));
+          pre_w[i] = v;
+        }
       }
     }
   };
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
     const int tn = t + (int)gridDim.x;
     const Tile nxt = tile_at(tn < ntiles ? tn : t);
 
-    for (int kc = 0; kc < a.KPad; kc += 32) {
+    for (int kc = 0; kc < kend; kc += 32) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
@@ -143,17 +158,42 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
           *reinterpret_cast<bf16x4*>(dst + LOFF) = lo;
         }
       }
+      const bool second = CENTER && kc >= a.KPad;
       if (w_in_regs) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
           const int p = tid + i * NT;
-          if (p < nw_pieces) *reinterpret_cast<u32x4*>(sm_w + (p >> 3) * ROW3 + (p & 7) * 16) = pre_w[i];
+          if (p < (second ? BMC * 8 : nw_pieces)) *reinterpret_cast<u32x4*>(sm_w + (p >> 3) * ROW3 + (p & 7) * 16) = pre_w[i];
         }
       }
       __syncthreads();
       // next stage: the next chunk of this tile, or the first chunk of the block's next tile
-      if (kc + 32 < a.KPad) fetch(cur, kc + 32, true);
-      else if (tn < ntiles) { w_in_regs = kch > 1; fetch(nxt, 0, w_in_regs); }
+      if (kc + 32 < kend) fetch(cur, kc + 32, true);
+      else if (tn < ntiles) { w_in_regs = CENTER || kch > 1; fetch(nxt, 0, w_in_regs); }
+
+      if constexpr (CENTER) {
+        if (second) {            // centre tap only: pixel (py + 1, px + 1) of the halo image, weights in the image of tap 0
+          const int toff = (a.LW + 1) * ROW3;
+          bf16x8 Ah[MI], Al[MI];
+#pragma unroll
+          for (int j = 0; j < MI; ++j) {
+            Ah[j] = *reinterpret_cast<const bf16x8*>(sm_w + w_off[j]);
+            Al[j] = *reinterpret_cast<const bf16x8*>(sm_w + w_off[j] + LOFF);
+          }
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff);
+            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + LOFF);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh, acc[j][i], 0, 0, 0);
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl, acc[j][i], 0, 0, 0);
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh, acc[j][i], 0, 0, 0);
+            }
+          }
+          continue;
+        }
+      }
 
       // one wave per SIMD: the fragments of tap t+1 are read while the MFMAs of tap t run (two register sets); with two
       // waves per SIMD the other wave covers the LDS latency and one set keeps the kernel inside 256 VGPRs
@@ -265,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
   }
 }
 
-template <int TAPS, int MI, int NI, int WM, int WN, int NPX>
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false>
 static int launch_x3(ConvArgs a, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int BMC = WM * MI * 16, TP = WN * NI * 16;
@@ -282,7 +322,7 @@ static int launch_x3(ConvArgs a, hipStream_t st) {
     return SX_ERR_UNSUPPORTED;
   }
   if ((int64_t)a.Hx * a.Wx * a.x_ld >= ((int64_t)1 << 31)) { set_error("conv: one sample exceeds 2^31 elements"); return SX_ERR_UNSUPPORTED; }
-  auto kern = conv_x3_kernel<TAPS, MI, NI, WM, WN, NPX>;
+  auto kern = conv_x3_kernel<TAPS, MI, NI, WM, WN, NPX, CENTER>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_x3)"));
   // persistent grid: as many blocks as the LDS images allow on 256 CUs (2 in flight per CU at least when they are small)
@@ -305,22 +345,27 @@ static int launch_x3(ConvArgs a, hipStream_t st) {
   return SX_OK;
 }
 
-template <int TAPS, int NPX>
+template <int TAPS, int NPX, bool CENTER = false>
 static int x3_tiles(const ConvArgs& a, hipStream_t st) {
-  if (a.RTot <= 16) return launch_x3<TAPS, 1, 2, 1, 4, NPX>(a, st);
-  if (a.RTot <= 32) return launch_x3<TAPS, 2, 2, 1, 4, NPX>(a, st);
+  if (a.RTot <= 16) return launch_x3<TAPS, 1, 2, 1, 4, NPX, CENTER>(a, st);
+  if (a.RTot <= 32) return launch_x3<TAPS, 2, 2, 1, 4, NPX, CENTER>(a, st);
   // 64 channels x 256 pixels on 8 waves where a sample has that many pixels in tiles of this width (half the weight
   // traffic per pixel: at one block per CU the 128-pixel form was bound by re-fetching 74 KB of weights per chunk)
   if constexpr (TAPS != 4) {
     constexpr int NPX8 = TAPS == 9 ? 6 : 4;
     const int th = 256 / a.TW;
-    if (a.H * a.TW >= 256 && (th + (TAPS == 9 ? 2 : 0)) * a.LW * 8 <= NPX8 * 512) return launch_x3<TAPS, 2, 4, 2, 4, NPX8>(a, st);
+    if (a.H * a.TW >= 256 && (th + (TAPS == 9 ? 2 : 0)) * a.LW * 8 <= NPX8 * 512) return launch_x3<TAPS, 2, 4, 2, 4, NPX8, CENTER>(a, st);
   }
-  return launch_x3<TAPS, 2, 4, 2, 2, NPX>(a, st);
+  return launch_x3<TAPS, 2, 4, 2, 2, NPX, CENTER>(a, st);
 }
 
-int conv_x3_dispatch(const ConvArgs& a, hipStream_t st) {
+int conv_x3_dispatch(const ConvArgs& a, hipStream_t st, int var) {
   if (a.KPad % 32) { set_error("conv_x3: packed K %d is not a multiple of 32", a.KPad); return SX_ERR_INVALID; }
+  if (var == WS_CENTER) {
+    if (a.ntaps != 9 || !a.w2 || a.K != a.KPad || a.x_ld < 2 * a.K || a.accumulate || a.gn_stats || a.bias || a.shuffle) return 1;   // 1 = not covered
+    return x3_tiles<9, 7, true>(a, st);
+  }
+  if (var != WS_PLAIN) return 1;
   // pieces per thread at 256 threads: the transposed convolution's data gradient gathers from a 16 x 32 pixel image (16),
   // everything else from at most 34 x 6 pixels (7)
   if (a.ntaps == 9) return x3_tiles<9, 7>(a, st);
