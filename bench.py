@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-tier leg (what amp=False runs), reported beside the headline")
     ap.add_argument("--no-infer", action="store_true", help="skip the forward-only leg (profiling runs of the training step)")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=24)
@@ -382,6 +383,25 @@ def main():
                                 "mfma_TFLOPs": round(tfs, 2), "mfma_frac": round(tfs / mfma_peak, 4)}
             step_flops = 7.272e9 * a.batch
             line["step_model_tflops"] = round(step_flops * a.steps / dt / 1e12, 2)
+        if not a.no_fp32 and world == 1 and a.dtype == "bf16":
+            # the fp32 tier (amp=False: what the reference's own scripts pass) on the same workload, beside the headline
+            m32 = make_model(0).to(dev).train()
+            e32 = TrainEngine(m32, dtype=torch.float32, lr=3e-4, weight_decay=1e-4, clip_grad=1.0, channel_weights=CHANNEL_WEIGHTS_8,
+                              w_map=w_map, loss_opts=LOSS)
+            for _ in range(5):
+                e32.train_step(x, y, m, p, lam_grad=LOSS["lam_grad"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = 20
+            for _ in range(n32):
+                e32.train_step(x, y, m, p, lam_grad=LOSS["lam_grad"])
+            torch.cuda.synchronize()
+            d32 = (time.perf_counter() - t1) / n32
+            exact = L.lib().sx_set_fp32_exact(-1)
+            line["fp32_tier"] = {"ms_per_step": round(1e3 * d32, 4), "samples_per_s": round(a.batch / d32, 1), "steps": n32,
+                                 "arithmetic": "exact fp32 MFMA" if exact else "split-bf16: bf16 hi + lo planes, 3 bf16 MFMAs per product block, fp32 accumulation",
+                                 "final_loss": float(e32.log[max(e32.nlog - 1, 0), 0])}
+            del e32, m32
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is a single-GPU-run item (rank 0, N = 1 only)
             # threads: the job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count() reports the whole
             # machine); "cores" = the threads the oracle actually ran on, host_cpu_count = what the host reports

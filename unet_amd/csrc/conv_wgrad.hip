@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
   constexpr int BA = MI * 16, BB = 64;
   constexpr int PROW = BA * 2 + 16, QROW = BB * 2 + 16;
   constexpr int PPIECES = BA / 4, QPIECES = BB / 4;        // 16-byte pieces of 4 fp32 per pixel
-  constexpr int NPP = 1024 / NT, NPQ = 2048 / NT;
+  constexpr int NPP = 1024 / NT, NPQ = (MI == 2 ? 3072 : 2048) / NT;      // MI = 2 also takes 128-pixel tiles (180-pixel halo)
   extern __shared__ __align__(16) char smem[];
   char* sPh = smem;
   char* sPl = sPh + a.TP * PROW;
@@ -368,18 +368,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
       }
       const int r0 = (((k0 >> a.tw_log2) * a.q_scale) * a.LW + (k0 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
       const int r1 = (((k1 >> a.tw_log2) * a.q_scale) * a.LW + (k1 & (a.TW - 1)) * a.q_scale) * QROW + p4 * 8;
+      // every lane issues the transposed reads (EXEC must be full); invalid items read item 0.  The fragments of item t+1
+      // are read under the MFMAs of item t (back to back, each item exposed the LDS latency: 18 times per tile)
+      bf16x8 Bh[2], Bl[2];
+      auto read_item = [&](int t, int slot) {
+        const int o0 = r0 + it_tap_off[t] + it_bf[t] * 32, o1 = r1 + it_tap_off[t] + it_bf[t] * 32;
+        Bh[slot] = Frag<bf16>::read(sQh + o0, sQh + o1);
+        Bl[slot] = Frag<bf16>::read(sQl + o0, sQl + o1);
+      };
+      read_item(0, 0);
 #pragma unroll
       for (int t = 0; t < ITEMS; ++t) {
-        // every lane issues the transposed reads (EXEC must be full); invalid items read item 0
-        const int o0 = r0 + it_tap_off[t] + it_bf[t] * 32, o1 = r1 + it_tap_off[t] + it_bf[t] * 32;
-        const bf16x8 Bh = Frag<bf16>::read(sQh + o0, sQh + o1);
-        const bf16x8 Bl = Frag<bf16>::read(sQl + o0, sQl + o1);
+        const int sl = t & 1;
+        if (t + 1 < ITEMS) read_item(t + 1, sl ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh, acc[t][j], 0, 0, 0);
-          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl, acc[t][j], 0, 0, 0);
-          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh, acc[t][j], 0, 0, 0);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh[sl], acc[t][j], 0, 0, 0);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl[sl], acc[t][j], 0, 0, 0);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh[sl], acc[t][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -517,7 +526,7 @@ static WgPlan wgrad_plan(int mode, int B, int H, int W, int Ca, int Cb, const Wg
   return p;
 }
 
-static int wgrad_geom(int mode, int dtype, int B, int H, int W, WgradArgs& a) {
+static int wgrad_geom(int mode, int dtype, int B, int H, int W, WgradArgs& a, int tp = 0) {
   switch (mode) {
     case SX_CONV3: a.ntaps = 9; a.tapw = 3; a.q_scale = 1; a.pad = 1; break;
     case SX_CONV1: a.ntaps = 1; a.tapw = 1; a.q_scale = 1; a.pad = 0; break;
@@ -529,6 +538,7 @@ static int wgrad_geom(int mode, int dtype, int B, int H, int W, WgradArgs& a) {
   // the transposed conv's Q tile is 4x the pixels of the P tile: keep the fp32 image inside LDS
   // fp32: 64-pixel tiles keep a block's two images under 80 KB of LDS, i.e. two blocks per CU (8.68 -> 8.29 ms per step)
   a.TP = (mode == SX_CONVT_FWD && dtype == SX_F32) ? 32 : (dtype == SX_F32 ? 64 : 128);
+  if (tp) a.TP = tp;
   a.TH = a.TP / a.TW;
   const int taph = a.ntaps / a.tapw;
   a.LW = (a.TW - 1) * a.q_scale + a.tapw;
@@ -576,7 +586,7 @@ static int launch_wgrad_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) 
   constexpr int PROW = MI * 16 * 2 + 16, QROW = 64 * 2 + 16;
   const size_t smem = 2 * ((size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW);
   if (smem > 160 * 1024) { set_error("wgrad tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
-  if (a.TP * MI * 4 > 4 * 256 || a.LH * a.LW * 16 > 8 * 256 || a.TP % 32) {     // the kernel's register-prefetch slots
+  if (a.TP * MI * 4 > 4 * 256 || a.LH * a.LW * 16 > (MI == 2 ? 12 : 8) * 256 || a.TP % 32) {     // the kernel's register-prefetch slots
     set_error("wgrad: fp32 tile of %d + %d pixels exceeds the prefetch slots", a.TP, a.LH * a.LW);
     return SX_ERR_UNSUPPORTED;
   }
@@ -648,6 +658,10 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
     }
   }
   static const int x3_blocks = env_int("SX_X3_WG_BLOCKS", 512);
+  // split-bf16 arithmetic, <= 48 output rows (the level-0 layers): 128-pixel tiles.  A 64-pixel tile's MFMAs (0.8 us) are
+  // shorter than the HBM latency of the next tile's register prefetch, and its halo over-fetch is 1.7x against 1.4x
+  static const int x3_tp = env_int("SX_X3_WG_TP", 128);
+  if (dtype == SX_F32 && fp32_split() && mode != SX_CONVT_FWD && round_up(Ca, 16) < 64 && x3_tp != 64) SX_TRY(wgrad_geom(mode, dtype, B, H, W, a, x3_tp));
   WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && fp32_split()) ? x3_blocks : 1024);
   SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
              (long long)slab_bytes, p.ws_bytes);
