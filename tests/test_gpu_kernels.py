@@ -273,7 +273,9 @@ def test_conv_transpose_forward_and_backward(L, dtype, B, h, w, Cin, Cout, Ho, W
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("mode,B,H,W,Cin,Cout", [(0, 2, 16, 8, 8, 16), (0, 3, 13, 7, 16, 24), (0, 2, 32, 16, 32, 64),
-                                                  (0, 1, 16, 16, 64, 128), (1, 2, 12, 10, 32, 16), (0, 4, 32, 32, 8, 32)])
+                                                  (0, 1, 16, 16, 64, 128), (1, 2, 12, 10, 32, 16), (0, 4, 32, 32, 8, 32),
+                                                  # 4-wide grids (32 x 4 pixel tiles: the largest halo), ragged 3-wide, 40 output rows
+                                                  (0, 2, 40, 4, 16, 16), (1, 2, 8, 4, 8, 32), (0, 3, 6, 3, 8, 8), (0, 2, 24, 20, 24, 40)])
 def test_conv_wgrad(L, dtype, mode, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(H + Cin + mode)
     k = 3 if mode == 0 else 1

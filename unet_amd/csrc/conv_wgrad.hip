@@ -661,7 +661,10 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
   // split-bf16 arithmetic, <= 48 output rows (the level-0 layers): 128-pixel tiles.  A 64-pixel tile's MFMAs (0.8 us) are
   // shorter than the HBM latency of the next tile's register prefetch, and its halo over-fetch is 1.7x against 1.4x
   static const int x3_tp = env_int("SX_X3_WG_TP", 128);
-  if (dtype == SX_F32 && fp32_split() && mode != SX_CONVT_FWD && round_up(Ca, 16) < 64 && x3_tp != 64) SX_TRY(wgrad_geom(mode, dtype, B, H, W, a, x3_tp));
+  if (dtype == SX_F32 && fp32_split() && mode != SX_CONVT_FWD && round_up(Ca, 16) < 64 && x3_tp != 64) {
+    SX_TRY(wgrad_geom(mode, dtype, B, H, W, a, x3_tp));
+    if (a.LH * a.LW * 16 > 12 * 256 || a.TP % 32) SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));      // 4-wide grids: the halo of a 32 x 4 tile exceeds the staging slots
+  }
   WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && fp32_split()) ? x3_blocks : 1024);
   SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
              (long long)slab_bytes, p.ws_bytes);
