@@ -633,3 +633,97 @@ def test_fp32_split_arithmetic_error_against_fp64(L, fp32_mode):
     assert e_y < bound and e_w < bound
     if fp32_mode == "split":
         assert e_y > 5e-7          # the split kernels really ran (the exact ones sit at ~2e-7)
+
+
+def _rand_shapes(n, seed):
+    """Seeded random problem shapes: every grid-width class (<= 4, <= 8, wider), ragged tiles, channel counts on and off the
+    16 / 32 / 64 boundaries."""
+    r = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        W = int(r.choice([2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 33]))
+        H = int(r.choice([1, 2, 5, 8, 13, 16, 31, 32, 40]))
+        Cin = int(r.choice([4, 8, 12, 16, 24, 32, 40, 64, 72, 128]))
+        Cout = int(r.choice([4, 8, 12, 16, 24, 32, 48, 64, 80, 128]))
+        B = int(r.choice([1, 2, 3, 5]))
+        out.append((B, H, W, Cin, Cout))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv_and_wgrad_random_shapes(L, fp32_mode, mode, dtype):
+    """Both tiers (fp32 in both arithmetic modes), 40 seeded random shapes per kernel size: forward (+ GroupNorm statistics), data gradient and weight gradient
+    of 3x3 / 1x1 convolutions against torch -- tile edges, 4- and 8-wide grids, K and row counts off the chunk sizes."""
+    k = 3 if mode == 0 else 1
+    md = L.SX_CONV3 if mode == 0 else L.SX_CONV1
+    for (B, H, W, Cin, Cout) in _rand_shapes(40, 100 + mode):
+        g = torch.Generator().manual_seed(B + 7 * H + 13 * W + Cin + 3 * Cout)
+        if dtype == 1 and (Cin % 8 or Cout % 8):
+            continue                                   # bf16 moves 8 channels per 16-byte piece
+        x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+        w = q(torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5), dtype)
+        dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+        tag = (dtype, mode, B, H, W, Cin, Cout)
+        pad_c = 4 if dtype == 0 else 8
+        tol = TOL[dtype]
+        ref = F.conv2d(x, w, padding=k // 2)
+        xd, dyd = nhwc(x, dtype, ld=Cin + pad_c), nhwc(dy, dtype)
+        y = torch.full((B, H, W, Cout + pad_c), 7.0, dtype=tdt(dtype), device="cuda")
+        G = 4 if Cout % 4 == 0 else 1
+        stats = torch.zeros(B, G, 2, dtype=torch.float32, device="cuda")
+        wp = pack(L, dtype, md, 0, w, Cout, Cin, Cout, Cin)
+        L.check(L.lib().sx_conv_forward(dtype, md, B, H, W, Cin, Cout, L.ptr(xd), Cin + pad_c, H, W, L.ptr(wp), None, L.ptr(y), Cout + pad_c,
+                                        H, W, 0, L.ptr(stats), G, L.stream_ptr()))
+        wpd = pack(L, dtype, md, 1, w, Cout, Cin, Cin, Cout)
+        dx = torch.empty(B, H, W, Cin, dtype=tdt(dtype), device="cuda")
+        L.check(L.lib().sx_conv_forward(dtype, md, B, H, W, Cout, Cin, L.ptr(dyd), Cout, H, W, L.ptr(wpd), None, L.ptr(dx), Cin, H, W,
+                                        0, None, 0, L.stream_ptr()))
+        nb = L.lib().sx_conv_wgrad_workspace_bytes(md, B, H, W, Cout, Cin)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device="cuda")
+        L.check(L.lib().sx_conv_wgrad(dtype, md, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin + pad_c, H, W, L.ptr(dw), 0,
+                                      L.ptr(ws), nb, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y, Cout), ref) < tol, tag
+        assert float((y[..., Cout:].float() - 7.0).abs().max()) == 0.0, tag
+        rg = ref.view(B, G, -1)
+        assert rel_err(stats.cpu(), torch.stack([rg.sum(-1), (rg * rg).sum(-1)], dim=-1)) < tol, tag
+        assert rel_err(from_nhwc(dx, Cin), torch.nn.grad.conv2d_input(x.shape, w, dy, padding=k // 2)) < tol, tag
+        assert rel_err(dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=k // 2)) < tol, tag
+
+
+def test_fp32_conv_transpose_random_shapes(L, fp32_mode):
+    """fp32 tier: ConvTranspose2d(2, 2) forward (+ bias), data gradient and weight gradient on 24 seeded random shapes."""
+    r = np.random.RandomState(5)
+    for _ in range(24):
+        B = int(r.choice([1, 2, 3])); h = int(r.choice([1, 3, 4, 8, 9, 16])); w = int(r.choice([1, 2, 4, 5, 8, 12, 17]))
+        Cin = int(r.choice([8, 16, 32, 64, 128])); Cout = int(r.choice([4, 8, 16, 32, 64]))
+        g = torch.Generator().manual_seed(B + 5 * h + 11 * w + Cin + Cout)
+        x = torch.randn(B, Cin, h, w, generator=g)
+        wt = torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5
+        bias = torch.randn(Cout, generator=g)
+        dy = torch.randn(B, Cout, 2 * h, 2 * w, generator=g)
+        tag = (B, h, w, Cin, Cout)
+        xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        ref = F.conv_transpose2d(xr, wr, bias, stride=2)
+        ref.backward(dy)
+        xd, dyd = nhwc(x, 0), nhwc(dy, 0)
+        y = torch.empty(B, 2 * h, 2 * w, Cout, dtype=torch.float32, device="cuda")
+        wp = pack(L, 0, L.SX_CONVT_FWD, 0, wt, Cout, Cin, Cout, Cin)
+        bd = bias.cuda()
+        L.check(L.lib().sx_conv_forward(0, L.SX_CONVT_FWD, B, h, w, Cin, Cout, L.ptr(xd), Cin, h, w, L.ptr(wp), L.ptr(bd),
+                                        L.ptr(y), Cout, 2 * h, 2 * w, 0, None, 0, L.stream_ptr()))
+        wpb = pack(L, 0, L.SX_CONVT_BWD, 0, wt, Cout, Cin, Cin, Cout)
+        dx = torch.empty(B, h, w, Cin, dtype=torch.float32, device="cuda")
+        L.check(L.lib().sx_conv_forward(0, L.SX_CONVT_BWD, B, h, w, Cout, Cin, L.ptr(dyd), Cout, 2 * h, 2 * w, L.ptr(wpb), None,
+                                        L.ptr(dx), Cin, h, w, 0, None, 0, L.stream_ptr()))
+        nb = L.lib().sx_conv_wgrad_workspace_bytes(L.SX_CONVT_FWD, B, h, w, Cin, Cout)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        dw = torch.empty(Cin, Cout, 2, 2, dtype=torch.float32, device="cuda")
+        L.check(L.lib().sx_conv_wgrad(0, L.SX_CONVT_FWD, B, h, w, Cin, Cout, Cin, Cout, L.ptr(xd), Cin, L.ptr(dyd), Cout,
+                                      2 * h, 2 * w, L.ptr(dw), 0, L.ptr(ws), nb, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y, Cout), ref.detach()) < 1e-4, tag
+        assert rel_err(from_nhwc(dx, Cin), xr.grad) < 1e-4, tag
+        assert rel_err(dw.cpu(), wr.grad) < 1e-4, tag

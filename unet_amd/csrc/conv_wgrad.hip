@@ -575,6 +575,7 @@ static int wgrad_items(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
     case 3: return launch_wgrad<T, MI, 3>(a, p, st);
     case 4: return launch_wgrad<T, MI, 4>(a, p, st);
     case 5: return launch_wgrad<T, MI, 5>(a, p, st);
+    case 7: return launch_wgrad<T, MI, 7>(a, p, st);      // 9 taps x 3 b fragments (33..48 input channels)
     case 9: return launch_wgrad<T, MI, 9>(a, p, st);
   }
   set_error("wgrad: unexpected item count %d", p.items);
@@ -606,6 +607,7 @@ static int wgrad_items_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
     case 3: return launch_wgrad_x3<MI, 3>(a, p, st);
     case 4: return launch_wgrad_x3<MI, 4>(a, p, st);
     case 5: return launch_wgrad_x3<MI, 5>(a, p, st);
+    case 7: return launch_wgrad_x3<MI, 7>(a, p, st);      // 9 taps x 3 b fragments (33..48 input channels)
     case 9:
       if constexpr (MI == 4) return launch_wgrad_x3<MI, 5, 8>(a, p, st);      // 36 items on eight waves
       else return launch_wgrad_x3<MI, 9>(a, p, st);
