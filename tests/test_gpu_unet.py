@@ -380,3 +380,57 @@ def test_sub_blocks_called_on_their_own_match_the_oracle(dtype, tol, B, Cin, Cc,
     assert rel_err(pd.grad.cpu(), pr.grad) < tol
     for k, p in gen.named_parameters():
         assert rel_err(p.grad.cpu(), gsd["f." + k].grad) < tol, k
+
+
+def _random_arch(seed):
+    r = np.random.RandomState(1000 + seed)
+    depth = int(r.choice([1, 2, 3, 4]))
+    base = int(r.choice([8, 16, 24, 32, 40, 48] if depth < 4 else [8, 16, 24]))
+    in_ch = int(r.choice([1, 2, 3, 10]))
+    out_ch = int(r.choice([1, 2, 4, 5, 8, 9]))
+    P = int(r.choice([0, 3, 5]))
+    lo = 1 << depth
+    H = int(r.randint(lo, 41))
+    W = int(r.randint(lo, 29))
+    B = int(r.choice([1, 2, 3]))
+    return dict(depth=depth, base=base, in_ch=in_ch, out_ch=out_ch, P=P, H=H, W=W, B=B)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_architectures_against_oracle(seed):
+    """Seeded random architectures (depth 1-4, base 8-48 -- channel counts on and off the 32-wide chunks --, odd grids, with and
+    without FiLM, 1-10 input and 1-9 output channels) in both tiers against the CPU oracle: prediction, loss and every
+    parameter gradient.  Smooth loss (see test_cfg5_shape_against_oracle).  bf16 gradients on these tiny grids (a few hundred
+    pixels, nothing averages the rounding of bf16-stored activations) are held to 15 %: eager PyTorch under bf16 autocast
+    lands at the same distance from fp32 on the same cases (first-layer weight gradient 8.5 % / 7.6 % against 10.0 % / 8.1 %
+    here, tools/chk_bf16_noise.py); the full-size bf16 bars (1e-2 / 6e-2) are in test_gpu_fullsize.py."""
+    from oracle import unet_ref, loss_ref
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from unet_amd.synth import make_batch
+    from unet_amd.losses import masked_weighted_loss
+    a = _random_arch(seed)
+    cfg = UNetCfg(in_ch=a["in_ch"], out_ch=a["out_ch"], base=a["base"], P=a["P"], film_hidden=32, depth=a["depth"])
+    sd = init_state_dict(cfg, seed=50 + seed)
+    bt = make_batch(a["B"], a["H"], a["W"], in_ch=a["in_ch"], out_ch=a["out_ch"], P=a["P"], seed=60 + seed, jitter_masks=True)
+    kw = dict(base="huber", huber_beta=0.05, lam_grad=0.0, lam_w=0.0)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    par = bt["params"] if a["P"] > 0 else None
+    o = unet_ref.unet_forward(sdr, cfg, bt["x"], par)
+    lr = loss_ref.masked_weighted_loss(o, bt["y"], bt["mask"], **kw)
+    lr.backward()
+    gmax = max(float(v.grad.norm()) for v in sdr.values() if v.grad is not None)
+    for dtype, tol_p, tol_g in ((torch.float32, 1e-4, 5e-4), (torch.bfloat16, 1.5e-2, 0.15)):
+        model = build(cfg, sd).train()
+        model.compute_dtype = dtype
+        pred = model(bt["x"].cuda(), params=par.cuda() if par is not None else None)
+        loss = masked_weighted_loss(pred, bt["y"].cuda(), bt["mask"].cuda(), **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert rel_err(pred.detach().float().cpu(), o.detach()) < tol_p, (a, str(dtype))
+        assert abs(float(loss) - float(lr)) < tol_p * abs(float(lr)), (a, str(dtype))
+        for k, p in model.named_parameters():
+            ref = sdr[k].grad
+            if ref is None:
+                continue
+            err = float((p.grad.cpu().double() - ref.double()).norm())
+            assert err < tol_g * max(float(ref.norm()), 0.05 * gmax), (a, str(dtype), k, err, float(ref.norm()))
