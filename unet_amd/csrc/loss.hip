@@ -322,12 +322,24 @@ struct FuseArgs {
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ __forceinline__ f32x2_ load2(const float* p) { return *reinterpret_cast<const f32x2_*>(p); }
+__device__ __forceinline__ f32x2_ load2(const bf16* p) {
+  const bf16x2_ v = *reinterpret_cast<const bf16x2_*>(p);
+  return f32x2_{(float)v[0], (float)v[1]};
+}
+__device__ __forceinline__ void store2(float* p, f32x2_ v) { *reinterpret_cast<f32x2_*>(p) = v; }
+__device__ __forceinline__ void store2(bf16* p, f32x2_ v) { *reinterpret_cast<bf16x2_*>(p) = bf16x2_{(bf16)v[0], (bf16)v[1]}; }
+static constexpr int FUSE_CG = 4;        // threads per pooling window in the fast instances (8 / FUSE_CG channels each)
 
 // 2 x 2 windows (grad_ds = 2, the production setting), C <= 8, even W: both pixels of a window row move as one 8-byte
 // (fp32 planes) or two 16-byte (NHWC bf16) accesses.  FAST = false: any window size / channel count, scalar accesses.
+// The fast instance gives a window to FUSE_CG threads, 8 / FUSE_CG channels each: one thread per window left the chip at two
+// waves per SIMD with ~25 long-latency accesses each (base_pool 28.5 us for 55 MB; two threads 20.0, four 19.9 us; grad_out 18.3 / 14.9 / 13.7 us).
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
-  constexpr int MC = FAST ? 8 : FUSE_MAXC;
+  constexpr int CG = FAST ? FUSE_CG : 1;
+  constexpr int MC = FAST ? 8 / FUSE_CG : FUSE_MAXC;
   float v[3] = {0.f, 0.f, 0.f};
   const float scw = cw_sum(a.cw, a.C);
   const float cb = 1.0f / fmaxf(a.den[0] * scw, 1e-8f);
@@ -337,10 +349,13 @@ __global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
   const float inv = 1.0f / (float)(k * k);
   const T* pred = reinterpret_cast<const T*>(a.pred);
   const int64_t n = (int64_t)a.B * gh * gw;
-  float cwv[MC];
+  GRID_STRIDE(ii, n * CG) {
+    const int cg = FAST ? (int)(ii / n) : 0;           // the channel group is the slow index: a wave stays inside one plane
+    const int c0 = cg * MC;                            // this thread's first channel
+    const int64_t i = ii - cg * n;
+    float cwv[MC];
 #pragma unroll
-  for (int c = 0; c < MC; ++c) cwv[c] = (c < a.C) ? (a.cw ? a.cw[c] : 1.f) : 0.f;
-  GRID_STRIDE(i, n) {
+    for (int c = 0; c < MC; ++c) cwv[c] = (c0 + c < a.C) ? (a.cw ? a.cw[c0 + c] : 1.f) : 0.f;
     const int x = (int)(i % gw);
     const int y = (int)((i / gw) % gh);
     const int b = (int)(i / ((int64_t)gw * gh));
@@ -354,14 +369,16 @@ __global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
         const f32x2_ mm = *reinterpret_cast<const f32x2_*>(a.m + (int64_t)b * hw + px);
         f32x2_ ww = {0.f, 0.f};
         if (a.w) ww = *reinterpret_cast<const f32x2_*>(a.w + px);
-        const T* pp = pred + ((int64_t)b * hw + px) * a.ld;
-        const f32x8 p0 = load8(pp), p1 = load8(pp + a.ld);
+        const T* pp = pred + ((int64_t)b * hw + px) * a.ld + c0;
+        f32x4 p0, p1;
+        if constexpr (MC == 4) { p0 = load4(pp); p1 = load4(pp + a.ld); }
+        else { const f32x2_ q0 = load2(pp), q1 = load2(pp + a.ld); p0 = f32x4{q0[0], q0[1], 0.f, 0.f}; p1 = f32x4{q1[0], q1[1], 0.f, 0.f}; }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (c < a.C) {
-            const int64_t e = ((int64_t)b * a.C + c) * hw + px;
+        for (int c = 0; c < MC; ++c) {
+          if (c0 + c < a.C) {
+            const int64_t e = ((int64_t)b * a.C + c0 + c) * hw + px;
             const f32x2_ tt = *reinterpret_cast<const f32x2_*>(a.t + e);
-            const float pr[2] = {p0.v[c], p1.v[c]};
+            const float pr[2] = {p0[c], p1[c]};
             f32x2_ go;
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
@@ -404,8 +421,8 @@ __global__ __launch_bounds__(256) void base_pool_kernel(FuseArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < MC; ++c)
-      if (c < a.C) {
-        const int64_t q = (((int64_t)b * a.C + c) * gh + y) * gw + x;
+      if (c0 + c < a.C) {
+        const int64_t q = (((int64_t)b * a.C + c0 + c) * gh + y) * gw + x;
         a.pg[q] = sp[c] * inv;
         a.tg[q] = st[c] * inv;
       }
@@ -460,13 +477,17 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
   // the numerators are complete (base_pool and sobel_fwd ran before this launch): block 0 finishes the loss value here
   // instead of a one-block launch of its own
   if (blockIdx.x == 0) loss_final_block(fin);
-  constexpr int MC = FAST ? 8 : FUSE_MAXC;
+  constexpr int CG = FAST ? FUSE_CG : 1;        // fast instance: FUSE_CG threads per window (as base_pool_kernel)
+  constexpr int MC = FAST ? 8 / FUSE_CG : FUSE_MAXC;
   const int k = FAST ? 2 : a.k;
   const int gh = a.H / k, gw = a.W / k, hw = a.H * a.W;
   const float inv = 1.0f / (float)(k * k);
   T* out = reinterpret_cast<T*>(a.dpred);
   const int64_t n = (int64_t)a.B * gh * gw;
-  GRID_STRIDE(i, n) {
+  GRID_STRIDE(ii, n * CG) {
+    const int cg = FAST ? (int)(ii / n) : 0;
+    const int c0 = cg * MC;
+    const int64_t i = ii - cg * n;
     const int x = (int)(i % gw);
     const int y = (int)((i / gw) % gh);
     const int b = (int)(i / ((int64_t)gw * gh));
@@ -474,9 +495,9 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
       d[c] = 0.f;
-      if (c < a.C) {
-        const float* X = a.ux + ((int64_t)b * a.C + c) * gh * gw;
-        const float* Y = a.uy + ((int64_t)b * a.C + c) * gh * gw;
+      if (c0 + c < a.C) {
+        const float* X = a.ux + ((int64_t)b * a.C + c0 + c) * gh * gw;
+        const float* Y = a.uy + ((int64_t)b * a.C + c0 + c) * gh * gw;
         float t = 0.f;
         t += -1.f * at0(X, gh, gw, y + 1, x + 1) + 1.f * at0(X, gh, gw, y + 1, x - 1);
         t += -2.f * at0(X, gh, gw, y, x + 1) + 2.f * at0(X, gh, gw, y, x - 1);
@@ -486,21 +507,21 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
         d[c] = t * inv;
       }
     }
-    if constexpr (FAST) {       // dld == 8: one 16-byte store per pixel, the plane gradient read as 8-byte pairs
+    if constexpr (FAST) {       // dld == 8: this thread's four channels of a pixel in one store, the plane gradient read as 8-byte pairs
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
         const int px = (y * 2 + dy) * a.W + x * 2;
-        f32x8 o0, o1;
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < MC; ++c) {
           f32x2_ gg = {0.f, 0.f};
-          if (c < a.C) gg = *reinterpret_cast<const f32x2_*>(a.g + ((int64_t)b * a.C + c) * hw + px);
-          o0.v[c] = c < a.C ? a.scale * (d[c] + gg[0]) : 0.f;
-          o1.v[c] = c < a.C ? a.scale * (d[c] + gg[1]) : 0.f;
+          if (c0 + c < a.C) gg = *reinterpret_cast<const f32x2_*>(a.g + ((int64_t)b * a.C + c0 + c) * hw + px);
+          o0[c] = c0 + c < a.C ? a.scale * (d[c] + gg[0]) : 0.f;
+          o1[c] = c0 + c < a.C ? a.scale * (d[c] + gg[1]) : 0.f;
         }
-        T* dst = out + ((int64_t)b * hw + px) * 8;
-        store8(dst, o0);
-        store8(dst + 8, o1);
+        T* dst = out + ((int64_t)b * hw + px) * 8 + c0;
+        if constexpr (MC == 4) { store4(dst, o0); store4(dst + 8, o1); }
+        else { store2(dst, f32x2_{o0[0], o0[1]}); store2(dst + 8, f32x2_{o1[0], o1[1]}); }
       }
     } else {
       for (int dy = 0; dy < k; ++dy)
@@ -681,9 +702,9 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
     f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
 #define SX_FUSE_LAUNCH(KERN, ...)                                                                               \
     do {                                                                                                        \
-      if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__);   \
+      if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(FUSE_CG * nwin)), dim3(256), 0, st, __VA_ARGS__);   \
                               else hipLaunchKernelGGL((KERN<bf16, false>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__); }     \
-      else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__);                   \
+      else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(FUSE_CG * nwin)), dim3(256), 0, st, __VA_ARGS__);                   \
              else hipLaunchKernelGGL((KERN<float, false>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__); }                     \
     } while (0)
     SX_FUSE_LAUNCH(base_pool_kernel, fa);
