@@ -160,3 +160,14 @@ def test_utils_helpers_have_the_reference_return_values(tmp_path):
     assert j == 1 and abs(d2 - 0.05) < 1e-12
     for name in ("pick_device", "sample_from_loader", "eval_param2z_one", "nearest_neighbor_in_Z"):   # solpex/__init__.py:11
         assert getattr(solpex, name) is getattr(unet_amd, name)
+
+
+def test_fp32_mode_switch_needs_no_gpu():
+    """unet_amd.fp32_exact / sx_set_fp32_exact: query, set, restore (host-side state of the library; no kernel runs)."""
+    import unet_amd
+    was = unet_amd.fp32_exact()
+    assert unet_amd.fp32_exact(True) == was
+    assert unet_amd.fp32_exact() is True
+    assert unet_amd.fp32_exact(False) is True
+    assert unet_amd.fp32_exact() is False
+    unet_amd.fp32_exact(was)

@@ -11,7 +11,7 @@ from .losses import edge_weights, masked_weighted_loss, mae_norm, batch_error_su
 from .train import train_unet, TrainEngine
 from .predict import load_checkpoint, predict_fields, predict_te, predict_fields_batch, scale_params
 from .utils import (pick_device, sample_from_loader, eval_param2z_one, nearest_neighbor_in_Z, scale_params_for_inference,
-                    save_geometry_h5)
+                    save_geometry_h5, fp32_exact)
 from .latent import (extract_z_dataset, ParamToZ, ZToParam, train_param2z, train_z2param,   # noqa: F811  (as the reference,
                      train_cycle_consistent)                                              # latent.ParamToZ wins)
 from .data import ResidentLoader
@@ -23,5 +23,5 @@ __all__ = [
     "masked_weighted_loss", "mae_norm", "batch_error_sums_ev", "train_unet", "TrainEngine", "load_checkpoint",
     "predict_fields", "predict_te", "predict_fields_batch", "scale_params", "pick_device", "sample_from_loader", "eval_param2z_one",
     "nearest_neighbor_in_Z", "scale_params_for_inference", "save_geometry_h5", "extract_z_dataset", "ZToParam", "train_param2z", "train_z2param",
-    "train_cycle_consistent", "ResidentLoader",
+    "train_cycle_consistent", "ResidentLoader", "fp32_exact",
 ]

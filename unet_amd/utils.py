@@ -94,3 +94,12 @@ def eval_param2z_one(*, ae, mlp, sample, device, label="", z_mu=None, z_std=None
     if label:
         print(f"[{label}] cos={res['cos']:.4f} |z_true|={res['z_true_norm']:.4g} |z_pred|={res['z_pred_norm']:.4g}")
     return res
+
+
+def fp32_exact(on=None):
+    """fp32 arithmetic of the convolution kernels (amp=False): False = split-bf16 (each operand as bf16 hi + lo, three bf16 MFMAs
+    per product block, ~4e-6 per convolution against fp64; the default), True = exact fp32 MFMA (1.7x slower per training step).
+    Returns the previous setting; `on=None` only queries.  The HIP build's counterpart of `torch.backends.cudnn.allow_tf32`
+    (no equivalent in the reference's own code); the environment variable SX_FP32_EXACT=1 sets it at start-up."""
+    from . import _lib as L
+    return bool(L.lib().sx_set_fp32_exact(-1 if on is None else int(bool(on))))
