@@ -1,6 +1,7 @@
 // FiLM generator launch descriptors shared by film.hip and unet_plan.hip.
 #pragma once
 #include "sx_common.h"
+#include "norm_act.h"
 
 namespace sx {
 
@@ -26,6 +27,11 @@ struct FilmArgs {
 };
 
 int film_forward(const FilmArgs& a, hipStream_t st);
-int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st);
+// gn (nullable): GroupNorm affine / bias gradient reductions of the same backward half.  In a training step (weight gradients
+// wanted, no gradient w.r.t. the FiLM inputs) ONE launch runs the dW2 rows, the dW1 rows -- each block rebuilding the dpre
+// values of its 16 hidden units itself instead of waiting for a phase-A launch -- and these reductions: three dispatches
+// (film_bwd_a 15 us, film_bwd_b 20 us, gn_param_grad 12 us) become one.  Returns with *gn_done = 1 when they rode along.
+int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st, const GnGradDesc* gn = nullptr, int n_gn = 0,
+                  int* gn_done = nullptr);
 
 }  // namespace sx

@@ -332,30 +332,8 @@ __global__ __launch_bounds__(256) void act_bwd_apply_kernel(ActArgs a) {
 
 // dgamma[c] (+)= sum_b sums[b][c][0] ; dbeta[c] (+)= sum_b sums[b][c][1]   for every GroupNorm of a descriptor table
 // block = 64 channels x 4 batch lanes (fixed-order LDS combine); one launch covers all layers of a backward half
-__global__ __launch_bounds__(256) void gn_param_grad_kernel(GnGradArgs A) {
-  __shared__ float red[2][4][64];
-  int di = 0;
-  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
-  const GnGradDesc& D = A.d[di];
-  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  const int c = ((int)blockIdx.x - D.blk0) * 64 + cl;
-  float g = 0.f, bt = 0.f;
-  const int nb = D.nb > 0 ? D.nb : A.B;
-  if (c < D.C)
-    for (int b = bl; b < nb; b += 4) {
-      const float* v = D.sums + ((int64_t)b * D.C + c) * D.stride;
-      g += v[0];
-      if (D.dbeta) bt += v[1];
-    }
-  red[0][bl][cl] = g;
-  red[1][bl][cl] = bt;
-  __syncthreads();
-  if (bl == 0 && c < D.C) {
-    g = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    bt = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-    D.dgamma[c] = A.accumulate ? D.dgamma[c] + g : g;
-    if (D.dbeta) D.dbeta[c] = A.accumulate ? D.dbeta[c] + bt : bt;
-  }
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const GnGradArgs) {
+  gn_param_grad_block((GnGradArgsK)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x);
 }
 
 int gn_param_grad_multi(const GnGradDesc* descs, int n, int B, int accumulate, hipStream_t st) {
@@ -363,12 +341,8 @@ int gn_param_grad_multi(const GnGradDesc* descs, int n, int B, int accumulate, h
     GnGradArgs A;
     A.n = std::min(GN_GRAD_MAX, n - i0);
     A.B = B; A.accumulate = accumulate;
-    int blk = 0;
-    for (int i = 0; i < A.n; ++i) {
-      A.d[i] = descs[i0 + i];
-      A.d[i].blk0 = blk;
-      blk += cdiv(A.d[i].C, 64);
-    }
+    for (int i = 0; i < A.n; ++i) A.d[i] = descs[i0 + i];
+    const int blk = gn_param_grad_layout(A);
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(blk), dim3(256), 0, st, A);
     SX_LAUNCH_CHECK("gn_param_grad");
   }

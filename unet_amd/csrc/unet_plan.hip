@@ -226,7 +226,7 @@ static int film_run_forward(const Plan& p, int k0, int k1, const float* const* p
 }
 
 static int film_run_backward(const Plan& p, int k0, int k1, const float* const* params, float* const* grads, void* ws,
-                             const float* film_params, int flags, hipStream_t st) {
+                             const float* film_params, int flags, hipStream_t st, std::vector<GnGradDesc>* gn = nullptr) {
   FilmArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
@@ -234,7 +234,11 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   fa.accumulate = (flags & SX_BWD_ACCUMULATE) ? 1 : 0;
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
   for (int k = k0; k < k1; ++k) film_fill(p, k, params, wg ? grads : nullptr, ws, fa.g[k - k0]);
-  return film_backward(fa, wg, st);
+  // gn: this half's GroupNorm affine / bias gradient reductions ride on the FiLM launch when it takes them (training steps)
+  int done = 0;
+  SX_TRY(film_backward(fa, wg, st, gn ? gn->data() : nullptr, gn ? (int)gn->size() : 0, &done));
+  if (gn && done) gn->clear();
+  return SX_OK;
 }
 
 // ---------------------------------------------------------------- weight-gradient queue
@@ -682,7 +686,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
   }
   const int ngen = (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1;
-  SX_TRY(wq.finish());
-  if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, st));
-  return SX_OK;
+  SX_TRY(wq.flush());
+  if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, st, &wq.gn));
+  return wq.finish_gn();        // whatever the FiLM launch did not take
 }
