@@ -182,6 +182,15 @@ int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, int groups,
                               const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
                               const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
                               void* r_out, int r_ld, void* pool, int pool_ld, void* stream);
+/* The same launch also recording, for every pooled value, its position inside the 2x2 window (0..3 = (dy << 1) | dx, one byte
+ * per pooled element in pool_idx[B][H/2][W/2][idx_ld], first maximum wins, a NaN beats any number -- ATen's rule, decided on
+ * the value as stored): sx_maxpool2_backward_add_idx routes the gradient with it and need not read the block output again
+ * (a third of that launch's traffic).  pool_idx may be null (then this is sx_block_out_pool_forward); idx_ld % 8 == 0,
+ * idx_ld >= C, pool_idx 8-byte aligned.  Replaces MaxPool2d's saved indices (`return_indices` inside autograd). */
+int sx_block_out_pool_idx_forward(int dtype, int B, int H, int W, int C, int groups, float eps, const void* y2, int y_ld,
+                                  const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                                  const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                                  void* r_out, int r_ld, void* pool, int pool_ld, void* pool_idx, int idx_ld, void* stream);
 /* mode | SX_GN_BWD_SUMS_READY: `sums` entries were already accumulated by the producer of d_out
  * (sx_conv_forward_gn_bwd_sums, sx_maxpool2_backward_gn_sums): only the element-wise phase runs. */
 #define SX_GN_BWD_SUMS_READY 4
@@ -208,6 +217,10 @@ int sx_unpack_output(int dtype, const void* in, int in_ld, int B, int C, int H, 
 int sx_maxpool2_forward(int dtype, int B, int H, int W, int C, const void* x, int x_ld, void* y, int y_ld, void* stream);
 int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, const void* x, int x_ld, const void* dp,
                              int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream);
+/* sx_maxpool2_backward_add with the window positions recorded by sx_block_out_pool_idx_forward instead of the pooled tensor's
+ * input (even H and W only): dx = dskip + scatter(dp). */
+int sx_maxpool2_backward_add_idx(int dtype, int B, int H, int W, int C, const void* pool_idx, int idx_ld, const void* dp,
+                                 int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream);
 int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, void* stream);
 int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, float* z, void* stream);
 int sx_zero_border(int dtype, int B, int H, int W, int Hin, int Win, int C, void* t, int ld, void* stream);

@@ -510,6 +510,64 @@ def test_maxpool_forward_backward_first_max_ties(L, dtype, B, H, W, Cc):
     assert rel_err(from_nhwc(dx, Cc), ref_dx) < (1e-6 if dtype == 0 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cc,film", [(2, 16, 8, 16, True), (3, 6, 10, 24, False), (2, 32, 16, 64, True), (1, 8, 8, 512, False)])
+def test_pool_positions_route_the_gradient_like_the_plain_backward(L, dtype, B, H, W, Cc, film):
+    """sx_block_out_pool_idx_forward records the window position of every pooled value; sx_maxpool2_backward_add_idx must give
+    bit-identical dx to sx_maxpool2_backward_add reading the block output itself -- with exact ties (first maximum wins), NaNs
+    (a NaN beats any number) and a strided output (the skip half of a concat buffer).  Outputs of the recording launch equal
+    the plain fused launch's."""
+    g = torch.Generator().manual_seed(Cc + 3 * H)
+    G = 8
+    y2 = q(torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.3, dtype)
+    y2[:, :, :2, :4] = 0.5                       # exact ties inside windows
+    s = q(torch.randn(B, Cc, H, W, generator=g), dtype)
+    s[:, :, :2, :4] = -0.25
+    s[0, 1, 2, 2] = float("nan")                 # a NaN in one window, second position
+    s[0, 2, 3, 3] = float("nan")                 # ... and in the last position of another
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda()
+    beta = (0.2 * torch.randn(Cc, generator=g)).cuda()
+    gf = (1 + 0.3 * torch.randn(B, Cc, generator=g)).cuda().contiguous()
+    bf = (0.3 * torch.randn(B, Cc, generator=g)).cuda().contiguous()
+    yg = y2.view(B, G, -1)
+    stats = torch.stack([yg.sum(-1), (yg * yg).sum(-1)], -1).cuda().contiguous()
+    yd, sd = nhwc(y2, dtype), nhwc(s, dtype)
+    lib = L.lib()
+    fg, fb = (L.ptr(gf), L.ptr(bf)) if film else (None, None)
+    outs = []
+    for rec in (False, True):
+        out = torch.zeros(B, H, W, 2 * Cc, dtype=tdt(dtype), device="cuda")
+        pool = torch.zeros(B, H // 2, W // 2, Cc, dtype=tdt(dtype), device="cuda")
+        idx = torch.full((B, H // 2, W // 2, Cc + 8), 9, dtype=torch.uint8, device="cuda")
+        L.check(lib.sx_block_out_pool_idx_forward(dtype, B, H, W, Cc, G, 1e-5, L.ptr(yd), Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                                  L.ptr(sd), Cc, fg, fb, None, L.ptr(out), 2 * Cc, None, 0, L.ptr(pool), Cc,
+                                                  L.ptr(idx) if rec else None, Cc + 8, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((out, pool, idx))
+    (o0, p0, _), (out, pool, idx) = outs
+    assert torch.equal(o0.view(torch.int16 if dtype == 1 else torch.int32), out.view(torch.int16 if dtype == 1 else torch.int32))
+    assert torch.equal(p0.view(torch.int16 if dtype == 1 else torch.int32), pool.view(torch.int16 if dtype == 1 else torch.int32))
+    assert int(idx[..., :Cc].max()) <= 3 and int(idx[..., Cc:].min()) == 9        # positions 0..3, padding bytes untouched
+    assert int(idx[:, 0, :2, :Cc].max()) == 0                                     # ties: the first element of the window
+    dP = nhwc(q(torch.randn(B, Cc, H // 2, W // 2, generator=g), dtype), dtype)
+    dskip = nhwc(q(torch.randn(B, Cc, H, W, generator=g), dtype), dtype)
+    dx0 = torch.empty(B, H, W, Cc, dtype=tdt(dtype), device="cuda")
+    dx1 = torch.empty_like(dx0)
+    L.check(lib.sx_maxpool2_backward_add(dtype, B, H, W, Cc, L.ptr(out), 2 * Cc, L.ptr(dP), Cc, L.ptr(dskip), Cc, L.ptr(dx0), Cc, L.stream_ptr()))
+    L.check(lib.sx_maxpool2_backward_add_idx(dtype, B, H, W, Cc, L.ptr(idx), Cc + 8, L.ptr(dP), Cc, L.ptr(dskip), Cc, L.ptr(dx1), Cc,
+                                             L.stream_ptr()))
+    torch.cuda.synchronize()
+    it = torch.int16 if dtype == 1 else torch.int32
+    assert torch.equal(dx0.view(it), dx1.view(it))
+    # without a skip gradient, and the refusals
+    L.check(lib.sx_maxpool2_backward_add(dtype, B, H, W, Cc, L.ptr(out), 2 * Cc, L.ptr(dP), Cc, None, 0, L.ptr(dx0), Cc, L.stream_ptr()))
+    L.check(lib.sx_maxpool2_backward_add_idx(dtype, B, H, W, Cc, L.ptr(idx), Cc + 8, L.ptr(dP), Cc, None, 0, L.ptr(dx1), Cc, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx0.view(it), dx1.view(it))
+    assert lib.sx_maxpool2_backward_add_idx(dtype, B, H + 1, W, Cc, L.ptr(idx), Cc + 8, L.ptr(dP), Cc, None, 0, L.ptr(dx1), Cc, L.stream_ptr()) != 0
+    assert lib.sx_maxpool2_backward_add_idx(dtype, B, H, W, Cc, L.ptr(idx), Cc + 4, L.ptr(dP), Cc, None, 0, L.ptr(dx1), Cc, L.stream_ptr()) != 0
+
+
 def test_loss_cases_match_golden(L, golden):
     """Every option combination of masked_weighted_loss: value and gradient vs the reference's vectors."""
     from unet_amd.losses import masked_weighted_loss, mae_norm

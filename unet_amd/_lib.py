@@ -53,12 +53,14 @@ SIGNATURES = {
     "sx_gn_silu_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p]),
     "sx_block_out_forward": (_i, [_i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "sx_block_out_pool_forward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
+    "sx_block_out_pool_idx_forward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sx_gn_silu_backward": (_i, [_i, _i, _i, _i, _i, _i, _f, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i,
                                  _p, _i, _p, _p, _i, _p]),
     "sx_pack_input": (_i, [_i, _p, _l, _l, _l, _l, _i, _i, _i, _i, _p, _i, _p]),
     "sx_unpack_output": (_i, [_i, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sx_maxpool2_forward": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p]),
     "sx_maxpool2_backward_add": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "sx_maxpool2_backward_add_idx": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sx_channel_sum": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "sx_global_avg_pool": (_i, [_i, _i, _i, _i, _p, _i, _p, _p]),
     "sx_gemm_f32": (_i, [_i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _l, _p, _i, _p, _l, _p, _l, _p, _l, _p, _i, _p]),

@@ -124,6 +124,37 @@ __global__ void maxpool_bwd_add_kernel(const T* __restrict__ x, int x_ld, const 
   }
 }
 
+// The same with the window positions recorded by the forward pass (sx_block_out_pool_idx_forward: one byte per pooled
+// element): the block output does not have to be read again to find them.  H and W even.
+template <typename T>
+__global__ void maxpool_bwd_add_idx_kernel(const unsigned char* __restrict__ idx, int idx_ld, const T* __restrict__ dp, int dp_ld,
+                                           const T* __restrict__ dskip, int ds_ld, T* __restrict__ dx, int dx_ld,
+                                           int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, slots = C >> 3;
+  const int64_t total = (int64_t)B * Ho * Wo * slots;
+  const bool small = total < ((int64_t)1 << 32);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c0, wx, wy, b;
+    split_item(i, small, slots, Wo, Ho, c0, wx, wy, b);
+    const int64_t win = ((int64_t)b * Ho + wy) * Wo + wx;
+    const f32x8 g = load8(dp + win * dp_ld + c0);
+    const unsigned long long ks = *reinterpret_cast<const unsigned long long*>(idx + win * idx_ld + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t pix = ((int64_t)b * H + 2 * wy + (k >> 1)) * W + 2 * wx + (k & 1);
+      f32x8 o;
+      if (dskip) o = load8(dskip + pix * ds_ld + c0);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if ((int)((ks >> (8 * e)) & 3) == k) o.v[e] += g.v[e];
+      store8(dx + pix * dx_ld + c0, o);
+    }
+  }
+}
+
 // out[c] (+)= sum over b, y < Hs, x < Ws of t[b,y,x,c]   (t is B x H x W, ld).  C % 8 == 0, C <= 2048:
 // each thread owns an 8-channel slot and walks pixels (16-byte loads), lanes combine through LDS.
 template <typename T>
@@ -223,6 +254,23 @@ extern "C" int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, c
   if (dtype == SX_BF16) hipLaunchKernelGGL(maxpool_bwd_add_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16*)x, x_ld, (const bf16*)dp, dp_ld, (const bf16*)dskip, ds_ld, (bf16*)dx, dx_ld, B, H, W, C);
   else hipLaunchKernelGGL(maxpool_bwd_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, x_ld, (const float*)dp, dp_ld, (const float*)dskip, ds_ld, (float*)dx, dx_ld, B, H, W, C);
   SX_LAUNCH_CHECK("maxpool_bwd_add");
+  return SX_OK;
+}
+
+extern "C" int sx_maxpool2_backward_add_idx(int dtype, int B, int H, int W, int C, const void* pool_idx, int idx_ld, const void* dp,
+                                            int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream) {
+  SX_REQUIRE(pool_idx && dp && dx, "sx_maxpool2_backward_add_idx: null pointer");
+  if (C % 8 || idx_ld % 8 || dp_ld % 8 || dx_ld % 8 || (dskip && ds_ld % 8) || (H & 1) || (W & 1) || H < 2 || W < 2 ||
+      ((uintptr_t)pool_idx % 8)) {
+    set_error("sx_maxpool2_backward_add_idx: need C %% 8 == 0, even H and W, 8-byte aligned positions");
+    return SX_ERR_UNSUPPORTED;
+  }
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned char* ix = (const unsigned char*)pool_idx;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(maxpool_bwd_add_idx_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, st, ix, idx_ld, (const bf16*)dp, dp_ld, (const bf16*)dskip, ds_ld, (bf16*)dx, dx_ld, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool_bwd_add_idx_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ix, idx_ld, (const float*)dp, dp_ld, (const float*)dskip, ds_ld, (float*)dx, dx_ld, B, H, W, C);
+  SX_LAUNCH_CHECK("maxpool_bwd_add_idx");
   return SX_OK;
 }
 

@@ -34,6 +34,7 @@ struct ActArgs {
   float eps;
   int pix_per_block;
   int W; void* pool; int p_ld;    // fused 2x2 max-pool of out0 (act_fwd_pool_kernel)
+  unsigned char* pidx; int pi_ld; // optional: position (0..3, first maximum) of each pooled value inside its window
 };
 
 // per-channel GN coefficients of sample b into LDS: n_hat = y * rs[c] - mr[c]; z = n_hat * ga[c] + be[c]
@@ -137,6 +138,8 @@ __global__ __launch_bounds__(256) void act_fwd_pool_kernel(ActArgs a) {
     const unsigned win = (unsigned)w0 + wq, wy = win / (unsigned)Wo, wx = win - wy * (unsigned)Wo;
     const int64_t pix0 = (int64_t)b * a.HW + (int64_t)(2 * wy) * a.W + 2 * wx;
     f32x8 y[4], sv[4], mx;
+    float bestv[8];
+    unsigned long long bestk = 0;      // eight 2-bit-in-a-byte positions
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t pix = pix0 + (k >> 1) * a.W + (k & 1);
@@ -152,11 +155,20 @@ __global__ __launch_bounds__(256) void act_fwd_pool_kernel(ActArgs a) {
         r.v[e] = (siluf_(y[k].v[e] * sc[c0 + e] + sh[c0 + e]) + sv[k].v[e]) * dr[c0 + e];
         o.v[e] = r.v[e] * fg[c0 + e] + fb[c0 + e];
         mx.v[e] = k ? fmaxf(mx.v[e], o.v[e]) : o.v[e];
+        // the position is decided on the value as STORED (what the backward pass of a separate max-pool would compare),
+        // first maximum wins, a NaN beats any number: ATen's rule (sx_maxpool2_backward_add applies the same one)
+        const float q = (float)(T)o.v[e];
+        if (k == 0) bestv[e] = q;
+        else if (q > bestv[e] || (q != q && bestv[e] == bestv[e])) {
+          bestv[e] = q;
+          bestk = (bestk & ~(0xffull << (8 * e))) | ((unsigned long long)k << (8 * e));
+        }
       }
       store8(O0 + pix * a.o0_ld + c0, o);
       if (O1) store8(O1 + pix * a.o1_ld + c0, r);
     }
     store8(P + ((int64_t)b * nwin + win) * a.p_ld + c0, mx);
+    if (a.pidx) *reinterpret_cast<unsigned long long*>(a.pidx + ((int64_t)b * nwin + win) * a.pi_ld + c0) = bestk;
   }
 }
 
@@ -422,9 +434,22 @@ extern "C" int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, 
                                          const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
                                          const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
                                          void* r_out, int r_ld, void* pool, int pool_ld, void* stream) {
+  return sx_block_out_pool_idx_forward(dtype, B, H, W, C, groups, eps, y2, y_ld, stats, gamma, beta, s, s_ld, film_g, film_b, drop,
+                                       out, out_ld, r_out, r_ld, pool, pool_ld, nullptr, 0, stream);
+}
+
+extern "C" int sx_block_out_pool_idx_forward(int dtype, int B, int H, int W, int C, int groups, float eps, const void* y2, int y_ld,
+                                             const float* stats, const float* gamma, const float* beta, const void* s, int s_ld,
+                                             const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
+                                             void* r_out, int r_ld, void* pool, int pool_ld, void* pool_idx, int idx_ld,
+                                             void* stream) {
   SX_REQUIRE(y2 && stats && gamma && beta && s && out && pool, "sx_block_out_pool_forward: null pointer");
   if (H < 2 || W < 2 || (H & 1) || (W & 1) || pool_ld % 8) {
     set_error("sx_block_out_pool_forward: needs even H, W and pool_ld %% 8 == 0 (H=%d W=%d)", H, W);
+    return SX_ERR_UNSUPPORTED;
+  }
+  if (pool_idx && (idx_ld % 8 || idx_ld < C || ((uintptr_t)pool_idx % 8))) {
+    set_error("sx_block_out_pool_idx_forward: pool_idx needs idx_ld %% 8 == 0, idx_ld >= C and an 8-byte aligned pointer");
     return SX_ERR_UNSUPPORTED;
   }
   ActArgs a;
@@ -432,6 +457,7 @@ extern "C" int sx_block_out_pool_forward(int dtype, int B, int H, int W, int C, 
   a.Y = y2; a.y_ld = y_ld; a.S = s; a.s_ld = s_ld; a.stats = stats; a.gamma = gamma; a.beta = beta;
   a.gf = film_g; a.bf = film_b; a.drop = drop; a.out0 = out; a.o0_ld = out_ld; a.out1 = r_out; a.o1_ld = r_ld;
   a.B = B; a.HW = H * W; a.C = C; a.G = groups; a.eps = eps; a.W = W; a.pool = pool; a.p_ld = pool_ld;
+  a.pidx = (unsigned char*)pool_idx; a.pi_ld = idx_ld;
   SX_TRY(act_check(a, "sx_block_out_pool_forward"));
   // chunks of windows: the grid rule sees a quarter of the pixels, each item being four of them
   ActArgs g = a;

@@ -29,6 +29,7 @@ struct BlockBuf {   // byte offsets into the workspace
                                     // two channel halves of ONE [B,H,W,2C] buffer (fused conv1 + shortcut data gradient)
   int64_t sums1, sums2;             // [B][C][4] fp32
   int64_t dX; int dx_ld;            // gradient w.r.t. the block input
+  int64_t pool_ix;                  // encoder levels: window position (0..3) of every pooled value, one byte each [B][H/2][W/2][C]
   int Cin, Cin_real, C, H, W, G;
   int64_t in; int in_ld;            // block input
   // packed weights (byte offsets into wpack)
@@ -142,6 +143,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
     if (k == 0) { b.dX = take((int64_t)B * b.H * b.W * p.in_pad * p.esz); b.dx_ld = p.in_pad; }   // d(input image), SX_BWD_INPUT_GRAD
     else if (k <= D) { b.dX = take((int64_t)B * b.H * b.W * b.Cin * p.esz); b.dx_ld = b.Cin; }   // = d(pool_{k-1})
     else { const int l = D - 1 - (k - D - 1); b.dX = p.dcat[l]; b.dx_ld = 2 * p.C[l]; }
+    b.pool_ix = k < D ? take((int64_t)B * (b.H / 2 + 1) * (b.W / 2 + 1) * b.C) : 0;
   }
   // statistics and backward sums: contiguous so one memset clears them
   p.stats_begin = off;
@@ -356,10 +358,11 @@ static int block_forward(const Plan& p, int k, const float* const* params, const
   const bool keep_r = film || drop;
   if (pool && !(b.H & 1) && !(b.W & 1)) {      // encoder block: its max-pooled output in the same pass
     *pooled = true;
-    return sx_block_out_pool_forward(dt, B, b.H, b.W, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
-                                     at(ws, b.S), b.C, film ? (const float*)at(ws, b.gf) : nullptr,
-                                     film ? (const float*)at(ws, b.bf) : nullptr, drop, at(ws, b.O), b.o_ld,
-                                     nullptr, 0, pool, pool_ld, st);
+    // (the window positions are recorded for the backward pass, which then need not read the block output again)
+    return sx_block_out_pool_idx_forward(dt, B, b.H, b.W, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2,
+                                         at(ws, b.S), b.C, film ? (const float*)at(ws, b.gf) : nullptr,
+                                         film ? (const float*)at(ws, b.bf) : nullptr, drop, at(ws, b.O), b.o_ld,
+                                         nullptr, 0, pool, pool_ld, at(ws, b.pool_ix), b.C, st);
   }
   SX_TRY(sx_block_out_forward(dt, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y2), b.C, (const float*)at(ws, b.st2), g2, be2, at(ws, b.S), b.C,
                               film ? (const float*)at(ws, b.gf) : nullptr, film ? (const float*)at(ws, b.bf) : nullptr, drop,
@@ -671,8 +674,12 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
   for (int l = D - 1; l >= 0; --l) {
     const BlockBuf& b = p.blk[l];
     const BlockBuf& nxt = p.blk[l + 1];   // its dX is d(pool_l)
-    SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
-                                    at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
+    if (!(p.H[l] & 1) && !(p.W[l] & 1))     // the forward pass pooled in its block-output launch and recorded the positions
+      SX_TRY(sx_maxpool2_backward_add_idx(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.pool_ix), p.C[l], at(ws, nxt.dX), nxt.dx_ld,
+                                          at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
+    else
+      SX_TRY(sx_maxpool2_backward_add(dt, B, p.H[l], p.W[l], p.C[l], at(ws, b.O), b.o_ld, at(ws, nxt.dX), nxt.dx_ld,
+                                      at(ws, p.dcat[l]) + (int64_t)p.C[l] * p.esz, 2 * p.C[l], at(ws, b.dO), p.C[l], stream));
     SX_TRY(block_backward(p, l, params, grads, wpack, ws, film, nullptr, l > 0 || (flags & SX_BWD_INPUT_GRAD), flags, wq, st));
   }
   if (wg && (flags & SX_BWD_DEFER_FILM))
