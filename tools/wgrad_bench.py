@@ -12,13 +12,18 @@ g = torch.Generator(device="cuda").manual_seed(0)
 st = torch.cuda.current_stream()
 C = [32, 64, 128, 256]
 HW = [(128, 64), (64, 32), (32, 16), (16, 8)]
+CIN0, COUT = 8, 8
+if os.environ.get("CFG") == "5":           # BASELINE configs[4]: base 64, 256x128, in 10 (padded 16), out 4 (padded 8)
+    C = [64, 128, 256, 512]
+    HW = [(256, 128), (128, 64), (64, 32), (32, 16)]
+    CIN0 = 16
 layers = []          # (mode, h, w, Ca (dY channels), Cb (input channels))
 for l in range(4):
-    cin = 8 if l == 0 else C[l - 1]
+    cin = CIN0 if l == 0 else C[l - 1]
     layers += [(0, *HW[l], C[l], cin), (0, *HW[l], C[l], C[l]), (1, *HW[l], C[l], cin)]
 for l in (2, 1, 0):
     layers += [(0, *HW[l], C[l], 2 * C[l]), (0, *HW[l], C[l], C[l]), (1, *HW[l], C[l], 2 * C[l]), (2, *HW[l + 1], C[l + 1], C[l])]
-layers.append((1, 128, 64, 8, 32))
+layers.append((1, *HW[0], COUT, C[0]))
 names = {0: "3x3", 1: "1x1", 2: "cT"}
 tot = 0.0
 for (mode, h, w, ca, cb) in layers:

@@ -402,7 +402,21 @@ static int wg_min_tiles(bool ct) { static const int v = env_int("SX_WG_MIN_TILES
 // 256 CUs alone: fewer, longer splits mean fewer slabs to write and to reduce
 // (measured on cfg A, batch 64: 256 blocks per problem 1.906 ms/step, 128: 1.846, 64: 1.807, 32: 1.820, 16: 1.97); a problem
 // launched on its own (sx_conv_wgrad) still spreads over the whole chip
-static int wg_target_blocks(bool batched) { static const int v = env_int("SX_WG_TARGET", 0); return batched ? (v > 0 ? v : 64) : 256; }
+// Large problems (cfg 5: 34-155 GFLOP per layer against <= 19 on cfg A) get blocks in proportion to their arithmetic instead:
+// at 64 blocks each the 13 problems of a half left the chip to a few 0.5 ms blocks (decoder half 1.45 ms at 22 % of the
+// MFMA peak; cfg 5 step 7.28 -> 6.70 ms with 100 MFLOP per block, 6.89 with 200, 6.95 with 400).  cfg A wants the opposite
+// (a block's fixed cost of ~8 us against 10-20 GFLOP problems: 1.68 ms per step at 400 MFLOP per block = 64 blocks each,
+// 1.69 at 200, 1.72 at 100), so the finer split starts at 30 GFLOP.  SX_WG_BLOCK_MFLOP overrides both; <= 512 blocks per
+// problem (the slab reservation, wgrad_ws_slab_bytes, covers whichever plan is larger).
+static constexpr int WG_MAX_BLOCKS = 512;
+static int wg_target_blocks(bool batched, double mflop) {
+  static const int v = std::min(std::max(env_int("SX_WG_TARGET", 0), 0), 256);
+  static const int per_block_env = env_int("SX_WG_BLOCK_MFLOP", 0);
+  if (!batched) return 256;
+  const int per_block = per_block_env > 0 ? per_block_env : (mflop > 30000.0 ? 100 : 400);
+  const int by_cost = (int)std::min<double>(WG_MAX_BLOCKS, mflop / per_block + 1.0);
+  return std::max(v > 0 ? v : 64, by_cost);
+}
 
 static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb, bool batched = false) {
   WgWsPlan p;
@@ -432,7 +446,7 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb, bool ba
   // layers pay for parallelism, and a block's fixed cost (~8 us) wants amortising anyway
   p.tg_count = 1;
   p.R = p.a_tiles * p.b_tiles;
-  int S = std::max(1, std::min(std::max(1, p.ntiles / wg_min_tiles(ct)), std::max(1, wg_target_blocks(batched) / p.R)));
+  int S = std::max(1, std::min(std::max(1, p.ntiles / wg_min_tiles(ct)), std::max(1, wg_target_blocks(batched, 2e-6 * p.ntiles * 128.0 * p.taps * p.CaPad * p.CbPad) / p.R)));
   p.tiles_per_split = cdiv(p.ntiles, S);
   p.S = cdiv(p.ntiles, p.tiles_per_split);
   p.slab_bytes = (int64_t)p.S * p.taps * p.CaPad * p.CbPad * 4;
@@ -470,8 +484,8 @@ static int launch_single(const WgWsLaunch& l, hipStream_t st) {
 }
 
 int64_t wgrad_ws_slab_bytes(int mode, int B, int H, int W, int Ca, int Cb) {
-  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb);
-  return p.ok ? p.slab_bytes : 0;
+  const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb), q = wgws_plan(mode, B, H, W, Ca, Cb, true);
+  return p.ok ? std::max(p.slab_bytes, q.slab_bytes) : 0;
 }
 
 // 0 = prepared (launch with wgrad_ws_launch), 1 = shape not covered
@@ -479,6 +493,8 @@ int wgrad_ws_prepare(int mode, int B, int H, int W, int Ca, int Cb, const void* 
                      float* slab, WgReduceDesc* desc, WgWsLaunch* out, int dual, int batched) {
   const WgWsPlan p = wgws_plan(mode, B, H, W, Ca, Cb, batched != 0);
   if (!p.ok) return 1;
+  // callers reserve wgrad_ws_slab_bytes() per problem: whatever plan runs must fit it (knobs included)
+  if (p.slab_bytes > wgrad_ws_slab_bytes(mode, B, H, W, Ca, Cb)) { set_error("wgrad_ws: plan needs %lld slab bytes, more than reserved", (long long)p.slab_bytes); return SX_ERR_INVALID; }
   if (dual && (mode != SX_CONV3 || p.MI != 4 || (p.NBF != 4 && p.NBF != 1) || p.a_tiles != 1 || p.b_tiles != 1 || p.TWL != 4 || Ca != 64)) return 1;
   WgWsArgs& a = out->a;
   memset(&a, 0, sizeof(a));
