@@ -47,4 +47,5 @@ for i, nme in enumerate(["setup", "wait first stage", "tile loop", "drain"]):
 loop = (s[:, 3] - s[:, 2])
 nst = s[:, 10].clamp(min=1)
 print(f"  per stage (median block): total {(loop / nst).median():7.0f}  = wait+barrier {(s[:, 7] / nst).median():6.0f} + DMA issue {(s[:, 8] / nst).median():6.0f}"
-      f" + LDS reads/MFMA {((loop - s[:, 7] - s[:, 8] - s[:, 9]) / nst).median():6.0f}; epilogue per tile {(s[:, 9] / s[:, 6].clamp(min=1)).median():6.0f}")
+      f" + LDS reads/MFMA {((loop - s[:, 7] - s[:, 8] - s[:, 9] - s[:, 11]) / nst).median():6.0f}; epilogue per tile {(s[:, 9] / s[:, 6].clamp(min=1)).median():6.0f}"
+      + (f"; partial-sum exchange per tile {(s[:, 11] / s[:, 6].clamp(min=1)).median():6.0f}" if float(s[:, 11].max()) > 0 else ""))

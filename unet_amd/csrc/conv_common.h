@@ -73,6 +73,52 @@ template <> struct Mma<float> {
 };
 
 
+// GroupNorm partial sums of a block's channels -> group sums -> one atomic per group and statistic.  sm_stat holds
+// [WN][BMC][2] per-channel (sum, sum of squares); called by every thread of the block after the barrier that publishes it.
+// Power-of-two group sizes: a butterfly over the lanes of a group.  (One thread walking its group's channels through LDS
+// was a chain of 2 * cpg dependent reads: ~6k cycles per flush at 32 channels per group, paid per TILE at the 16x8 level --
+// round-3 ablation stamps, profiles/r03_conv_kq_stamps.txt.)  Other sizes keep the walk.
+template <int BMC, int WN>
+__device__ __forceinline__ void gn_stats_flush(const float* sm_stat, int tid, int cb, int R, int cpg, float* stats_b) {
+  const int cend = min(R, cb + BMC);
+  if ((BMC & (BMC - 1)) == 0 && (cpg & (cpg - 1)) == 0) {
+    if ((tid >> 6) * 64 < BMC) {
+      const int c = cb + tid;
+      float t1 = 0.f, t2 = 0.f;
+      if (c < cend) {
+#pragma unroll
+        for (int w = 0; w < WN; ++w) {
+          t1 += sm_stat[(w * BMC + tid) * 2 + 0];
+          t2 += sm_stat[(w * BMC + tid) * 2 + 1];
+        }
+      }
+      const int seg = min(min(cpg, BMC), 64);      // divides cpg and BMC (powers of two): a segment never straddles groups
+      for (int o = 1; o < seg; o <<= 1) {
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
+      }
+      if (c < cend && (tid & (seg - 1)) == 0) {
+        atomicAdd(stats_b + (c / cpg) * 2 + 0, t1);
+        atomicAdd(stats_b + (c / cpg) * 2 + 1, t2);
+      }
+    }
+  } else if (tid < BMC) {
+    const int c = cb + tid;
+    if (c < cend && (tid == 0 || (c % cpg) == 0)) {
+      const int grp = c / cpg;
+      float t1 = 0.f, t2 = 0.f;
+      for (int cc = c; cc < cend && cc / cpg == grp; ++cc)
+#pragma unroll
+        for (int w = 0; w < WN; ++w) {
+          t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
+          t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
+        }
+      atomicAdd(stats_b + grp * 2 + 0, t1);
+      atomicAdd(stats_b + grp * 2 + 1, t2);
+    }
+  }
+}
+
 // weights-stationary bf16 fast path (conv_ws.hip); returns SX_ERR_UNSUPPORTED-free "not handled" as 1
 // WS_GATHER: the data gradient of ConvTranspose2d(2,2) as a 1x1 convolution over K = 4 taps x Cin gathered from the
 // fine grid (output pixel (y, x), tap (ty, tx) reads input pixel (2y + ty, 2x + tx)).

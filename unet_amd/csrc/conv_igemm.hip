@@ -203,23 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
   if (do_stats) {
     __syncthreads();
-    if (tid < BMC) {
-      const int c = cb + tid;
-      const int cend = min(a.R, cb + BMC);
-      if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
-        const int grp = c / a.cpg;
-        float t1 = 0.f, t2 = 0.f;
-        for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
-#pragma unroll
-          for (int w = 0; w < WN; ++w) {
-            t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
-            t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
-          }
-        const int G = a.R / a.cpg;
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
-      }
-    }
+    gn_stats_flush<BMC, WN>(sm_stat, tid, cb, a.R, a.cpg, a.gn_stats + (int64_t)b * (a.R / a.cpg) * 2);
   }
 }
 

@@ -308,23 +308,7 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
     // raw barrier: __syncthreads() would drain the LDS-DMA prefetches (vmcnt(0)); only LDS writes matter here
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (tid < BMC) {
-      const int c = cb + tid;
-      const int cend = min(a.R, cb + BMC);
-      if (c < cend && (tid == 0 || (c % a.cpg) == 0)) {
-        const int grp = c / a.cpg;
-        float t1 = 0.f, t2 = 0.f;
-        for (int cc = c; cc < cend && cc / a.cpg == grp; ++cc)
-#pragma unroll
-          for (int w = 0; w < WN; ++w) {
-            t1 += sm_stat[(w * BMC + (cc - cb)) * 2 + 0];
-            t2 += sm_stat[(w * BMC + (cc - cb)) * 2 + 1];
-          }
-        const int G = a.R / a.cpg;
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 0, t1);
-        atomicAdd(a.gn_stats + ((int64_t)b * G + grp) * 2 + 1, t2);
-      }
-    }
+    gn_stats_flush<BMC, WN>(sm_stat, tid, cb, a.R, a.cpg, a.gn_stats + (int64_t)b * (a.R / a.cpg) * 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // sm_stat may be rewritten by the next flush
   };
