@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-tier leg (what amp=False runs), reported beside the headline")
     ap.add_argument("--no-infer", action="store_true", help="skip the forward-only leg (profiling runs of the training step)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config5 / config4 / epoch legs")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=24)
     return ap.parse_args()
@@ -56,15 +57,20 @@ def make_model(seed=0):
     return m
 
 
-def conv_launches(B):
+ARCH_A = dict(C=[32, 64, 128, 256], Hs=[(128, 64), (64, 32), (32, 16), (16, 8)], cin0=8, cin0_real=1, out_pad=8)
+ARCH_B = dict(C=[64, 128, 256, 512], Hs=[(256, 128), (128, 64), (64, 32), (32, 16)], cin0=16, cin0_real=10, out_pad=8)   # BASELINE configs[4]
+
+
+def conv_launches(B, arch=ARCH_A):
     """Every launch of the dominant kernel (conv_ws_kernel, the weights-stationary implicit-GEMM convolution) in one
-    training step of cfg A: (kind, H, W, Cin, Cout, algorithmic flops).
+    training step of cfg A (or, with ARCH_B, of the plasma-to-sources network of BASELINE configs[4], where the 512-channel
+    layers run as two K halves and one fused form falls back to two launches: the closures below call the same C-ABI entry
+    points as the step, whatever they launch): (kind, H, W, Cin, Cout, algorithmic flops).
     kind: "dual" = conv1 3x3 + 1x1 shortcut forward (one launch), "c3"/"c1" = plain 3x3 / 1x1 (forward or data gradient),
     "center" = joint data gradient of conv1 + shortcut, "ct" = ConvTranspose2d(2,2) forward (four 1x1 GEMMs + pixel
     shuffle, H x W = its INPUT grid), "ctb" = its data gradient (a 1x1 over 4 taps x Cin gathered from the fine grid).
     Flops count the REAL channels (the 1-channel input is padded to 8).  The weight gradients run in wgrad_ws_kernel."""
-    C = [32, 64, 128, 256]
-    Hs = [(128, 64), (64, 32), (32, 16), (16, 8)]
+    C, Hs = arch["C"], arch["Hs"]
     out = []
 
     def block(hw, cin, cin_real, c, need_dx):
@@ -73,19 +79,19 @@ def conv_launches(B):
         out.append(("dual", h, w, cin, c, px * cin_real * c * 10))        # conv1 + shortcut forward
         out.append(("c3", h, w, c, c, px * c * c * 9))                     # conv2 forward
         # conv2 data gradient; where the kernel covers it, with GroupNorm-1's backward sums fused (reads Y1 as well)
-        out.append(("c3" if c == 128 else "c3bs", h, w, c, c, px * c * c * 9))
+        out.append(("c3" if c >= 128 else "c3bs", h, w, c, c, px * c * c * 9))
         if need_dx:
             out.append(("center", h, w, c, cin, px * cin_real * c * 10))   # conv1 + shortcut data gradient
     for l in range(4):                                                     # encoders + bottleneck
-        block(Hs[l], 8 if l == 0 else C[l - 1], 1 if l == 0 else C[l - 1], C[l], l > 0)
+        block(Hs[l], arch["cin0"] if l == 0 else C[l - 1], arch["cin0_real"] if l == 0 else C[l - 1], C[l], l > 0)
     for l in (2, 1, 0):                                                    # decoders
         h, w = Hs[l + 1]
         out.append(("ct", h, w, C[l + 1], C[l], 2.0 * B * h * w * C[l + 1] * C[l] * 4))
         block(Hs[l], 2 * C[l], 2 * C[l], C[l], True)
         out.append(("ctb", h, w, C[l], C[l + 1], 2.0 * B * h * w * C[l + 1] * C[l] * 4))   # its data gradient (H x W = its OUTPUT grid)
     h, w = Hs[0]
-    out.append(("c1", h, w, 8, 32, 2.0 * B * h * w * 32 * 8))             # head data gradient (the head's forward has a bias:
-    return out                                                            # conv_igemm_kernel)
+    out.append(("c1", h, w, arch["out_pad"], C[0], 2.0 * B * h * w * C[0] * arch["out_pad"]))   # head data gradient (the head's forward
+    return out                                                                                  # has a bias: conv_igemm_kernel)
 
 
 def conv_launch_maker(B, sx_dtype):
@@ -155,7 +161,7 @@ def conv_launch_maker(B, sx_dtype):
     return make
 
 
-def measure_conv_roofline(B, sx_dtype, reps=5):
+def measure_conv_roofline(B, sx_dtype, reps=5, arch=ARCH_A):
     """Replay every conv_ws_kernel launch of a step, in sequence, through the C ABI between HIP events (torch events on
     the stream the kernels are launched on).  Returns (flops, seconds, launches, bytes): bytes = algorithmic HBM traffic (every input
     tensor read once, every output written once, packed weights once)."""
@@ -163,7 +169,7 @@ def measure_conv_roofline(B, sx_dtype, reps=5):
     total_fl, total_s, n, total_by = 0.0, 0.0, 0, 0.0
     st = torch.cuda.current_stream()
     launches = []
-    for (kind, h, w, cin, cout, fl) in conv_launches(B):
+    for (kind, h, w, cin, cout, fl) in conv_launches(B, arch):
         launch, tensors = make(kind, h, w, cin, cout)
         launches.append(launch)
         total_fl += fl
@@ -206,15 +212,125 @@ def measure_infer(model, x, p, dtype, steps, warmup, world, sync, dev):
     return world * x.shape[0] * steps / dt
 
 
+TRAFFIC_FILE = "profiles/r02_conv_ws_traffic.json"
+
+
 def conv_traffic(a):
     """HBM bytes per step of the same launches from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, collected in separate
     rocprofv3 --pmc runs of this file and committed under profiles/: tools/pmc_traffic.py).  Only valid for the
-    configuration it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r02_conv_ws_traffic.json")
+    configuration it was collected on; NOT measured by this run (the JSON line says so: `traffic_source`)."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     if a.batch != 64 or a.dtype != "bf16" or not os.path.exists(path):
         return None
     with open(path) as f:
         return float(json.load(f)["hbm_bytes_per_step"])
+
+
+def config5_leg(dev, L, batch=32, steps=8):
+    """BASELINE configs[4]: plasma-to-sources U-Net (in 10, out 4, base 64, depth 3, no FiLM) at 256x128, full training step
+    (production loss, clip, AdamW) in both tiers, and the convolution family of one step replayed between HIP events.
+    scripts/run_source_from_plasma_pipeline.py:199-345."""
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.synth import make_batch
+    from unet_amd.losses import edge_weights
+    bt = make_batch(batch, 256, 128, in_ch=10, out_ch=4, P=0, seed=3)
+    x, y, m = (bt[k].to(dev) for k in ("x", "y", "mask"))
+    w_map = torch.from_numpy(edge_weights(bt["mask"][0, 0].numpy(), 3.0))
+    out = {"workload": "BASELINE configs[4]: plasma-to-sources U-Net (in 10, out 4, base 64, depth 3, P 0), 256x128, full training "
+                       f"step, batch {batch}", "flops_per_sample_step": 116.85e9}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        torch.manual_seed(0)
+        model = UNet(in_ch=10, out_ch=4, base=64, P=0, depth=3).to(dev).train()
+        eng = TrainEngine(model, dtype=dt, lr=3e-4, weight_decay=1e-4, clip_grad=1.0, w_map=w_map, loss_opts=LOSS)
+        for _ in range(3):
+            eng.train_step(x, y, m, None, lam_grad=LOSS["lam_grad"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.train_step(x, y, m, None, lam_grad=LOSS["lam_grad"])
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        out[name] = {"ms_per_step": round(1e3 * d, 3), "samples_per_s": round(batch / d, 1), "steps": steps,
+                     "model_TFLOPs": round(116.85e9 * batch / d / 1e12, 1), "final_loss": float(eng.log[eng.nlog - 1, 0])}
+        del eng, model
+    out["bf16"]["mfma_frac_of_step"] = round(out["bf16"]["model_TFLOPs"] / 2500.0, 4)
+    fl, secs, n, nbytes = measure_conv_roofline(batch, L.SX_BF16, reps=3, arch=ARCH_B)
+    tfs = fl / secs / 1e12
+    # 640 flop per byte: above the machine balance (312), so this family is priced against the dense bf16 MFMA peak
+    out["roofline"] = {"kernel": "every convolution entry point of one step (conv_ws_kernel; 512-channel layers as two K halves)",
+                       "bound": "mfma", "achieved": round(tfs, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tfs / 2500.0, 4),
+                       "traffic": None, "calls_per_step": n, "flops_per_step": fl, "bytes_per_step": nbytes,
+                       "seconds_per_step": round(secs, 6)}
+    return out
+
+
+def config4_leg(dev, n=1024, steps=10):
+    """BASELINE configs[3] on one GPU: batched inverse, 1024 problems per chunk (the per-GPU share of 8192 over 8 GPUs), forward +
+    per-sample fit + data-gradient-only backward + per-sample Adam.  scripts/eval_inverse_cycle_conditional_unet.py:355-416."""
+    from unet_amd.inverse import batched_inverse
+    from unet_amd.synth import make_batch
+    model = make_model(0).to(dev).eval()
+    model.compute_dtype = torch.bfloat16
+    bt = make_batch(n, H, W, seed=7)
+    mask, p_true = bt["mask"].to(dev), bt["params"].to(dev)
+    with torch.no_grad():
+        y = torch.cat([model(mask[i:i + 64], params=p_true[i:i + 64]).float() for i in range(0, n, 64)])
+    p0 = torch.zeros_like(p_true)
+    batched_inverse(model, mask, y, p0, steps=2, early_stop_patience=0, batch=n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = batched_inverse(model, mask, y, p0, steps=steps, early_stop_patience=0, batch=n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rate = n * steps / dt
+    return {"workload": f"BASELINE configs[3], one GPU's share: batched inverse, {n} problems per chunk, 128x64, bf16, Adam + cosine",
+            "problem_steps_per_s": round(rate, 1), "ms_per_chunk_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "model_TFLOPs": round(4.846e9 * rate / 1e12, 1), "flops_per_problem_step": 4.846e9, "mean_fit": float(r["fit"].mean())}
+
+
+def epoch_leg(dev, n_train=1984, batch=64):
+    """train_unet (the reference's entry point, solpex/train.py:14-359) fed by the device-resident loader over a synthetic
+    SOLPS-shaped npz: does the data path keep up with the step?  Per-epoch time = (5 epochs - 1 epoch) / 4, each run
+    including validation on one batch and the best-checkpoint write."""
+    import contextlib
+    import io
+    import tempfile
+    import numpy as np
+    from unet_amd import data as D
+    from unet_amd.train import train_unet
+    from unet_amd.synth import CHANNEL_WEIGHTS_8
+    n = n_train + batch
+    rng = np.random.default_rng(0)
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rho = np.sqrt(((ii - H / 2) / (0.47 * H)) ** 2 + ((jj - W / 2) / (0.45 * W)) ** 2)
+    mask = ((rho >= 0.45) & (rho <= 1.0)).astype(np.float32)
+    keys = ["Te", "Ti", "ne", "ua", "Sp", "Qe", "Qi", "Sm"]
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "synth.npz")
+    np.savez(path, Y=np.abs(rng.normal(size=(n, 8, H, W))).astype(np.float32) * 10, y_keys=np.array(keys), mask=mask,
+             X=rng.normal(size=(n, 5)).astype(np.float32))
+    norms = {k: D.MaskedLogStandardizer(eps=1.0) for k in keys}
+    with contextlib.redirect_stdout(io.StringIO()):
+        tl, vl, norm, P, hw, scaler, pt, pk = D.make_loaders(path, batch_size=batch, y_keys=keys, norms_by_name=norms, device=str(dev),
+                                                             resident=True, split=1.0 - batch / n)
+
+        def run(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            train_unet(tl, vl, norm, 1, dev, out_ch=8, epochs=epochs, base=32, P=P, film_hidden=128, depth=3, lam_grad=0.1, lam_w=0.5,
+                       multiscale=0, amp=True, lr_init=3e-4, channel_weights=CHANNEL_WEIGHTS_8, param_scaler=scaler,
+                       save_path=os.path.join(tmp, "best.pt"), lam_grad_warmup_start=0, lam_grad_warmup_end=0)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run(1)
+        t1 = run(1)
+        t5 = run(5)
+    ntr = len(tl.dataset) if hasattr(tl, "dataset") else n_train
+    per = (t5 - t1) / 4
+    return {"workload": f"train_unet(amp=True) + ResidentLoader, {n_train} training samples per epoch, batch {batch}, validation on "
+                        f"{batch}, best-checkpoint writes", "samples_per_s": round(n_train / per, 1), "ms_per_epoch": round(1e3 * per, 2),
+            "first_epoch_run_s": round(t1, 3)}
 
 
 def cpu_baseline(batch, steps):
@@ -378,7 +494,9 @@ def main():
             # the family is bounded by HBM, so that is the roofline quoted; the MFMA view rides along
             line["roofline"] = {"kernel": "conv_ws_kernel (every launch of one step: 3x3 / 1x1 / transposed forward, 3x3 / 1x1 / transposed data gradients)",
                                 "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                "frac": round(gbs / 8000.0, 4), "traffic": conv_traffic(a), "launches_per_step": n,
+                                "frac": round(gbs / 8000.0, 4), "traffic": conv_traffic(a),
+                                "traffic_source": TRAFFIC_FILE + " (PMC passes of an earlier run of this workload, not this run)",
+                                "launches_per_step": n,
                                 "bytes_per_step": nbytes, "flops_per_step": fl, "seconds_per_step": round(secs, 6),
                                 "mfma_TFLOPs": round(tfs, 2), "mfma_frac": round(tfs / mfma_peak, 4)}
             step_flops = 7.272e9 * a.batch
@@ -402,6 +520,13 @@ def main():
                                  "arithmetic": "exact fp32 MFMA" if exact else "split-bf16: bf16 hi + lo planes, 3 bf16 MFMAs per product block, fp32 accumulation",
                                  "final_loss": float(e32.log[max(e32.nlog - 1, 0), 0])}
             del e32, m32
+        if not a.no_extra and world == 1 and a.dtype == "bf16":
+            # the other BASELINE configurations and the end-to-end epoch, a few steps each, beside the headline
+            del eng
+            torch.cuda.empty_cache()
+            line["config5"] = config5_leg(dev, L)
+            line["config4"] = config4_leg(dev)
+            line["epoch"] = epoch_leg(dev)
         if not a.no_cpu_baseline and world == 1:      # the CPU leg is a single-GPU-run item (rank 0, N = 1 only)
             # threads: the job's CPU share (OMP_NUM_THREADS is set to it on the GPU box, where os.cpu_count() reports the whole
             # machine); "cores" = the threads the oracle actually ran on, host_cpu_count = what the host reports

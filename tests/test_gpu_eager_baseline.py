@@ -117,16 +117,20 @@ def test_latent_cycle_trainer_step_vs_eager_torch_on_the_same_gpu():
     opt = latent_ref._Opt([sd_a, sd_b], 1e-3, 1e-4)
     Zd, Pdv = torch.from_numpy(Z).cuda(), torch.from_numpy(P).cuda()
 
-    def eager_epoch():
+    e_rows = []
+
+    def eager_epoch(record=False):
         for i in range(0, N, bs):
             z, p = Zd[i:i + bs], Pdv[i:i + bs]
             t0_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_b, z), p)
             t1_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_a, p), z)
             t2_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_b, latent_ref.mlp_forward(sd_a, p)), p)
             t3_ = latent_ref.smooth_l1(latent_ref.mlp_forward(sd_a, latent_ref.mlp_forward(sd_b, z)), z)
+            if record:
+                e_rows.append(torch.stack([t0_, t1_, t2_, t3_]).detach())
             (t0_ + t1_ + 0.1 * (t2_ + t3_)).backward()
             opt.step()
-    eager_epoch()
+    eager_epoch(record=True)                # the untimed first epoch: its loss trajectory is what the HIP side must reproduce
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eager_epoch()
@@ -140,8 +144,13 @@ def test_latent_cycle_trainer_step_vs_eager_torch_on_the_same_gpu():
         for i in range(0, N, bs):
             HL._cycle_losses(eng, p2z, z2p, Zd[i:i + bs], Pdv[i:i + bs], 0.1, True)
             eng.step()
-        eng.read()
-    hip_epoch()
+        return eng.read()[0]
+    h_rows = hip_epoch()
+    # same weights, same batches, same optimizer: the four loss terms of every step of the first epoch (40 AdamW steps)
+    e_np = torch.stack(e_rows).double().cpu().numpy()
+    assert h_rows.shape == e_np.shape
+    assert abs(h_rows[0] - e_np[0]).max() < 1e-5 * abs(e_np[0]).max()          # step 0: same weights, forward only
+    assert abs(h_rows - e_np).max() < 2e-3 * abs(e_np).max(), (h_rows[-1], e_np[-1])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hip_epoch()

@@ -163,3 +163,90 @@ def test_config4_chunk1024_against_oracle(dtype, tol_hist, tol_p):
         assert np.allclose(hist[:, n], np.asarray(losses), rtol=tol_hist, atol=atol), (n, hist[:, n], losses)
         assert float((res["p_scaled"][n].cpu() - p_fin).abs().max()) < tol_p, (n, res["p_scaled"][n].cpu(), p_fin)
         assert abs(float(res["fit"][n]) - fit) < 10 * tol_hist * abs(fit) + atol, (n, float(res["fit"][n]), fit)
+
+
+@pytest.fixture(scope="module")
+def cfg5_case():
+    """BASELINE configs[4] at its OWN grid: in 10 / out 4 / base 64 / depth 3 / no FiLM, 256x128, two samples with different
+    masks, production loss; one oracle step (~0.25 TFLOP on the host cores)."""
+    from oracle.unet_ref import UNetCfg, init_state_dict
+    from oracle import loss_ref
+    from unet_amd.synth import make_batch
+    torch.set_num_threads(16)
+    cfg = UNetCfg(in_ch=10, out_ch=4, base=64, P=0, depth=3)
+    sd = init_state_dict(cfg, seed=21)
+    bt = make_batch(2, 256, 128, in_ch=10, out_ch=4, P=0, seed=6, jitter_masks=True)
+    bt["params"] = None
+    w = torch.from_numpy(loss_ref.edge_weights(bt["mask"][0, 0].numpy()))
+    ref = _oracle_step(cfg, sd, bt, w, None)
+    return cfg, sd, bt, w, ref
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_g,cos_min", [(torch.float32, 1e-4, 5e-4, 0.999999), (torch.bfloat16, 1e-2, 6e-2, 0.998)])
+def test_cfg5_full_grid_train_step_against_oracle(cfg5_case, dtype, tol_loss, tol_g, cos_min, fp32_mode):
+    """The plasma-to-sources network at 256x128 (tiles_y x tiles_x = 32 x 8 at level 0, the 512-channel bottleneck, K = 4608
+    in the decoder's first convolution -- the longest contraction the envelope allows): loss, mae_norm, gradient norm and
+    every parameter gradient of TrainEngine.train_step against one oracle step (scripts/run_source_from_plasma_pipeline.py:199-345,
+    solpex/models.py:186-203)."""
+    import json
+    import os
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    cfg, sd, bt, w, (loss_ref_v, g_ref, _, gnorm_ref, mae_ref, _) = cfg5_case
+    model = UNet(in_ch=10, out_ch=4, base=64, P=0, depth=3)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    eng = TrainEngine(model, dtype=dtype, lr=LR, weight_decay=WD, clip_grad=CLIP, w_map=w, loss_opts=LOSS)
+    x, y, m = (bt[k].cuda() for k in ("x", "y", "mask"))
+    out = eng.train_step(x, y, m, None, lam_grad=LOSS["lam_grad"])
+    torch.cuda.synchronize()
+    loss = float(out[0])
+    assert abs(loss - loss_ref_v) < tol_loss * abs(loss_ref_v), (loss, loss_ref_v)
+    mae = float(out[1]) / max(float(out[2]), 1e-8)
+    assert abs(mae - mae_ref) < max(tol_loss, 1e-4) * mae_ref, (mae, mae_ref)
+    assert abs(float(eng.gnorm) - gnorm_ref) < tol_g * gnorm_ref, (float(eng.gnorm), gnorm_ref)
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    worst = (0.0, "")
+    for k, q in model.named_parameters():
+        gd, rd = q.grad.detach().cpu().double().reshape(-1), g_ref[k].double().reshape(-1)
+        err = float((gd - rd).norm()) / max(float(rd.norm()), 0.05 * gmax if dtype == torch.bfloat16 else 1e-3 * gmax)
+        worst = max(worst, (err, k))
+        assert err < tol_g, (k, err, float(rd.norm()))
+        if float(rd.norm()) > 0.05 * gmax:
+            assert float(torch.dot(gd, rd) / (gd.norm() * rd.norm())) > cos_min, k
+    print(f"[cfg5 256x128 {dtype} {fp32_mode}] loss {loss:.6f} vs {loss_ref_v:.6f}; worst gradient {worst}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/cfg5_parity_{str(dtype).split('.')[-1]}_{fp32_mode}.json", "w") as f:
+        json.dump({"loss": loss, "loss_oracle": loss_ref_v, "worst_gradient_rel": worst[0], "worst_gradient": worst[1],
+                   "gnorm": float(eng.gnorm), "gnorm_oracle": gnorm_ref}, f)
+
+
+def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode):
+    """The same step with the Sobel-L1 term switched off (its sign() turns last-bit prediction differences into O(1e-3)
+    gradient differences): what is left is the arithmetic of the convolutions themselves -- the figure for the 1e-4 bar at
+    the longest contraction of the envelope (K = 512 x 9), split-bf16 and exact fp32 MFMA."""
+    import json
+    from oracle import unet_ref, loss_ref
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    cfg, sd, bt, w, _ = cfg5_case
+    opts = dict(LOSS, lam_grad=0.0)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_r = loss_ref.masked_weighted_loss(unet_ref.unet_forward(sdr, cfg, bt["x"], None), bt["y"], bt["mask"], w=w, **opts)
+    loss_r.backward()
+    model = UNet(in_ch=10, out_ch=4, base=64, P=0, depth=3)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    eng = TrainEngine(model, dtype=torch.float32, lr=LR, weight_decay=WD, clip_grad=CLIP, w_map=w, loss_opts=opts)
+    out = eng.train_step(*(bt[k].cuda() for k in ("x", "y", "mask")), None, lam_grad=0.0)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(loss_r)) < 1e-5 * abs(float(loss_r))
+    gmax = max(float(v.grad.norm()) for v in sdr.values())
+    worst = (0.0, "")
+    for k, q in model.named_parameters():
+        gd, rd = q.grad.detach().cpu().double().reshape(-1), sdr[k].grad.double().reshape(-1)
+        worst = max(worst, (float((gd - rd).norm()) / max(float(rd.norm()), 1e-3 * gmax), k))
+    print(f"[cfg5 256x128 fp32 {fp32_mode}, smooth loss] worst gradient {worst}")
+    with open(f"gpurun_out/cfg5_parity_smooth_{fp32_mode}.json", "w") as f:
+        json.dump({"worst_gradient_rel": worst[0], "worst_gradient": worst[1]}, f)
+    assert worst[0] < 1e-4, worst

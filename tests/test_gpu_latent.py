@@ -55,6 +55,42 @@ def test_mlp_forward_and_gradients_through_autograd(golden):
         p2z.cpu()(t(g["P_va"]))
 
 
+def test_cycle_losses_with_dropout_against_oracle_with_the_same_masks():
+    """train_cycle_consistent's step with dropout > 0 (solpex/latent.py:243-251): the reference evaluates p2z(p) and z2p(z)
+    again, with fresh masks, inside the cycle terms.  Six forward runs, each through its own masks: the four loss values
+    and every parameter gradient against the oracle fed the masks the HIP path drew."""
+    from oracle import latent_ref
+    from unet_amd import latent as HL
+    torch.manual_seed(11)
+    p2z = HL.ParamToZ(5, 24, hidden=(32, 16), dropout=0.2).cuda().train()
+    z2p = HL.ZToParam(24, 5, hidden=(40, 24), dropout=0.25, use_layernorm=True).cuda().train()
+    z, p = torch.randn(21, 24), torch.randn(21, 5)
+    lam = 0.1
+    eng = HL._Trainer([p2z, z2p], 1e-3, 1e-4, torch.device("cuda"))
+    ctxs = HL._cycle_losses(eng, p2z, z2p, z.cuda(), p.cuda(), lam, True)
+    torch.cuda.synchronize()
+    mk = {k: [b["mask"].cpu() for b in c.blocks[:-1]] for k, c in ctxs.items()}
+    assert ctxs["inv_in"] is not ctxs["inv"] and not torch.equal(mk["inv_in"][0], mk["inv"][0])     # fresh masks
+    sa = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in p2z.state_dict().items()}
+    sb = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in z2p.state_dict().items()}
+    f = latent_ref.mlp_forward
+    t_fwd = latent_ref.smooth_l1(f(sb, z, mk["fwd"]), p)
+    t_inv = latent_ref.smooth_l1(f(sa, p, mk["inv"]), z)
+    t_pzp = latent_ref.smooth_l1(f(sb, f(sa, p, mk["inv_in"]), mk["pzp"]), p)
+    t_zpz = latent_ref.smooth_l1(f(sa, f(sb, z, mk["fwd_in"]), mk["zpz"]), z)
+    (t_fwd + t_inv + lam * (t_pzp + t_zpz)).backward()
+    row = eng.log[0].cpu()
+    for got, ref in zip(row, (t_fwd, t_inv, t_pzp, t_zpz)):
+        assert abs(float(got) - float(ref)) < 1e-5 * max(abs(float(ref)), 1e-3)
+    for m, sd in ((p2z, sa), (z2p, sb)):
+        for k, q in m.named_parameters():
+            assert rel_err(eng.grads[q].cpu(), sd[k].grad) < 1e-4, k
+    # eval mode: no masks, two runs per MLP as before
+    p2z.eval(); z2p.eval()
+    c2 = HL._cycle_losses(eng, p2z, z2p, z.cuda(), p.cuda(), lam, False)
+    assert c2["inv_in"] is c2["inv"] and c2["fwd_in"] is c2["fwd"]
+
+
 def test_layernorm_dropout_mlp_against_oracle_with_the_same_masks():
     from oracle import latent_ref
     from unet_amd.latent import ZToParam

@@ -36,7 +36,7 @@ def _norm():
     return D.MultiChannelNormalizer(keys, norms)
 
 
-def test_train_unet_two_epochs_match_reference_history(golden, tmp_path):
+def test_train_unet_two_epochs_match_reference_history(golden, tmp_path, fp32_mode):
     """Same loaders, weights and kwargs as tools/make_golden.py::train_case (fp32): history, final weights,
     checkpoint keys; then the deploy-style round trip load_checkpoint -> predict_fields."""
     from oracle.unet_ref import UNetCfg, init_state_dict

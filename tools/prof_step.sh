@@ -5,7 +5,7 @@ tag=$1
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $root/gpurun_out/$tag
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/$tag -- python3 $root/bench.py --no-infer --no-cpu-baseline --no-roofline --no-fp32 --steps 20 --warmup 5 $PROF_ARGS > $root/gpurun_out/$tag.log 2>&1 || exit 1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/$tag -- python3 $root/bench.py --no-infer --no-cpu-baseline --no-roofline --no-fp32 --no-extra --steps 20 --warmup 5 $PROF_ARGS > $root/gpurun_out/$tag.log 2>&1 || exit 1
 db=$(find $root/gpurun_out/$tag -name "*_results.db" | head -1)
 python3 $root/tools/prof_summary.py $db 25 > $root/gpurun_out/${tag}_kernels.txt
 python3 $root/tools/prof_cats.py $db 25 > $root/gpurun_out/${tag}_families.txt

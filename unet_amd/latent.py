@@ -311,30 +311,43 @@ def train_z2param(*, Z_train, P_train, Z_val, P_val, model, device, lr=1e-3, epo
 def _cycle_losses(eng, p2z, z2p, z, p, lam, train):
     """The four SmoothL1 terms of latent.py:243-251 into one log row [fwd, inv, cyc_pzp, cyc_zpz]; with `train`, the
     gradients of fwd + inv + lam * (cyc_pzp + cyc_zpz) accumulate into the arena.  Without dropout the reference's second
-    evaluations of p2z(p) and z2p(z) inside the cycle terms equal the first ones, so each MLP runs twice, not three times."""
-    if train and (_has_dropout(p2z) or _has_dropout(z2p)):
-        raise NotImplementedError("train_cycle_consistent (HIP): dropout > 0 inside the cycle terms is not implemented")
+    evaluations of p2z(p) and z2p(z) inside the cycle terms equal the first ones, so each MLP runs twice, not three times.
+    With dropout > 0 (training) they do not: the reference draws fresh masks for every call, so the inner p2z(p) / z2p(z) of
+    the cycle terms are evaluated on their own, three runs per MLP, each back-propagated through its own masks.
+    Returns the forward contexts (tests read the masks that were drawn)."""
+    resample = train and (_has_dropout(p2z) or _has_dropout(z2p))
     row = eng.new_row(z.shape[0])
     c_fwd = z2p.hip_forward(z, train)                  # z2p(z)           vs p
     c_inv = p2z.hip_forward(p, train)                  # p2z(p)           vs z
-    c_pzp = z2p.hip_forward(c_inv.out, train)          # z2p(p2z(p))      vs p
-    c_zpz = p2z.hip_forward(c_fwd.out, train)          # p2z(z2p(z))      vs z
+    c_inv_in = p2z.hip_forward(p, train) if resample else c_inv       # the p2z(p) inside z2p(p2z(p))
+    c_fwd_in = z2p.hip_forward(z, train) if resample else c_fwd       # the z2p(z) inside p2z(z2p(z))
+    c_pzp = z2p.hip_forward(c_inv_in.out, train)       # z2p(p2z(p))      vs p
+    c_zpz = p2z.hip_forward(c_fwd_in.out, train)       # p2z(z2p(z))      vs z
+    ctxs = dict(fwd=c_fwd, inv=c_inv, inv_in=c_inv_in, fwd_in=c_fwd_in, pzp=c_pzp, zpz=c_zpz)
     if not train:
         eng.loss(c_fwd.out, p, row[0:1])
         eng.loss(c_inv.out, z, row[1:2])
         eng.loss(c_pzp.out, p, row[2:3])
         eng.loss(c_zpz.out, z, row[3:4])
-        return
+        return ctxs
     g_pzp, g_zpz = torch.empty_like(c_pzp.out), torch.empty_like(c_zpz.out)
     eng.loss(c_pzp.out, p, row[2:3], g_pzp, weight=lam)
     eng.loss(c_zpz.out, z, row[3:4], g_zpz, weight=lam)
     eng.flat_g.zero_()
     g_inv = z2p.hip_backward(c_pzp, g_pzp, eng.grads, need_dx=True)      # gradient reaching p2z(p) through the cycle
     g_fwd = p2z.hip_backward(c_zpz, g_zpz, eng.grads, need_dx=True)      # gradient reaching z2p(z) through the cycle
-    eng.loss(c_fwd.out, p, row[0:1], g_fwd, accumulate=True)             # + the direct terms
-    eng.loss(c_inv.out, z, row[1:2], g_inv, accumulate=True)
+    if resample:
+        p2z.hip_backward(c_inv_in, g_inv, eng.grads)                     # the cycle terms' own inner evaluations
+        z2p.hip_backward(c_fwd_in, g_fwd, eng.grads)
+        g_fwd, g_inv = torch.empty_like(c_fwd.out), torch.empty_like(c_inv.out)
+        eng.loss(c_fwd.out, p, row[0:1], g_fwd)                          # the direct terms on theirs
+        eng.loss(c_inv.out, z, row[1:2], g_inv)
+    else:
+        eng.loss(c_fwd.out, p, row[0:1], g_fwd, accumulate=True)         # + the direct terms
+        eng.loss(c_inv.out, z, row[1:2], g_inv, accumulate=True)
     z2p.hip_backward(c_fwd, g_fwd, eng.grads)
     p2z.hip_backward(c_inv, g_inv, eng.grads)
+    return ctxs
 
 
 def _has_dropout(m):
@@ -401,32 +414,27 @@ def extract_z_dataset(*, ae_model, dataset, device, batch_size=64, num_workers=0
         loader, dataset = dataset, dataset.dataset
     else:
         loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
-    Zs, Ps, Is, seen = [], [], [], 0
+    def batch_params(batch):
+        """(B, P) float32 numpy: from the batch itself, else looked up in the dataset by the batch's indices"""
+        if "params" in batch:
+            return batch["params"].detach().to("cpu", torch.float32).numpy()
+        if "idx" not in batch or not hasattr(dataset, "params"):
+            raise KeyError("Need params for param→z: provide batch['params'] or batch['idx'] with dataset.params.")
+        rows = batch["idx"].detach().cpu().numpy() if torch.is_tensor(batch["idx"]) else batch["idx"]
+        return np.asarray(dataset.params[np.asarray(rows, dtype=int)], dtype=np.float32)
+
+    z_parts, p_parts = [], []
     for bi, batch in enumerate(loader):
+        if max_batches is not None and bi >= max(int(max_batches), 1):      # (the reference always takes the first batch)
+            break
         x = batch["x"].to(device)
-        params = batch["params"].to(device) if "params" in batch else None
-        _, b = ae_model(x, params=params, return_bottleneck=True)
-        z_t = bottleneck_to_z(b)
+        cond = batch["params"].to(device) if "params" in batch else None
+        _, bott = ae_model(x, params=cond, return_bottleneck=True)
+        z_t = bottleneck_to_z(bott)
         if getattr(ae_model, "z_proj", None) is not None:
             z_t = ae_model.z_proj(z_t)
-        z = z_t.detach().float().cpu().numpy()
-        Zs.append(z)
-        if "params" in batch:
-            p = batch["params"].detach().float().cpu().numpy()
-        elif "idx" in batch and hasattr(dataset, "params"):
-            ii = batch["idx"]
-            if torch.is_tensor(ii):
-                ii = ii.detach().cpu().numpy()
-            p = dataset.params[np.asarray(ii, dtype=int)].astype(np.float32, copy=False)
-        else:
-            raise KeyError("Need params for param→z: provide batch['params'] or batch['idx'] with dataset.params.")
-        Ps.append(p)
-        bs = z.shape[0]
-        Is.append(np.arange(seen, seen + bs, dtype=np.int64))
-        seen += bs
-        if max_batches is not None and (bi + 1) >= max_batches:
-            break
-    Z = np.concatenate(Zs, axis=0).astype(np.float32, copy=False)
-    P = np.concatenate(Ps, axis=0).astype(np.float32, copy=False)
-    idxs = np.concatenate(Is, axis=0).astype(np.int64, copy=False)
-    return Z, P, idxs
+        z_parts.append(z_t.detach().to("cpu", torch.float32).numpy())
+        p_parts.append(batch_params(batch))
+    Z = np.ascontiguousarray(np.concatenate(z_parts, axis=0), dtype=np.float32)
+    P = np.ascontiguousarray(np.concatenate(p_parts, axis=0), dtype=np.float32)
+    return Z, P, np.arange(Z.shape[0], dtype=np.int64)        # running positions, as the reference numbers them
