@@ -254,6 +254,8 @@ def config5_leg(dev, L, batch=32, steps=8):
         out[name] = {"ms_per_step": round(1e3 * d, 3), "samples_per_s": round(batch / d, 1), "steps": steps,
                      "model_TFLOPs": round(116.85e9 * batch / d / 1e12, 1), "final_loss": float(eng.log[eng.nlog - 1, 0])}
         del eng, model
+    out["fp32"]["arithmetic"] = ("exact fp32 MFMA: networks whose widest layer reaches 512 channels leave the split-bf16 kernels "
+                                 "(measured 4.1e-4 worst gradient error there against the 1e-4 contract; unet_plan.hip)")
     out["bf16"]["mfma_frac_of_step"] = round(out["bf16"]["model_TFLOPs"] / 2500.0, 4)
     fl, secs, n, nbytes = measure_conv_roofline(batch, L.SX_BF16, reps=3, arch=ARCH_B)
     tfs = fl / secs / 1e12
@@ -416,6 +418,13 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     local = local % max(torch.cuda.device_count(), 1)      # rehearsals: several gloo ranks on one card (SX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
+    # SX_DP_FORCE=1 on one GPU: a ONE-rank RCCL group, so that the whole data-parallel protocol of the step (asynchronous
+    # denominator all-reduce, three gradient buckets, split encoder backward) runs against real RCCL kernels and its cost on
+    # one card goes on record (`dp` in the JSON line; profiles/r03_dp_force.json)
+    forced = world == 1 and os.environ.get("SX_DP_FORCE", "0") not in ("", "0")
+    if forced and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+    dp_on = world > 1 or forced
     dev = torch.device("cuda", local)
     L.lib()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -427,7 +436,7 @@ def main():
                       w_map=w_map, loss_opts=LOSS)
 
     def sync():
-        if world > 1:
+        if dp_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -449,7 +458,7 @@ def main():
     value = world * a.batch * a.steps / dt
     infer = None if a.no_infer else measure_infer(model, x, p, dtype, a.steps, a.warmup, world, sync, dev)
     dp_diag = None
-    if world > 1:
+    if dp_on:
         # diagnostic for the scaling runs: the same step with every collective switched off (each rank on its own from here
         # on -- after the timed region, nothing reads these weights again).  The difference is the communication the
         # three-bucket overlap did NOT hide.
@@ -466,7 +475,10 @@ def main():
         eng.dp = True
         dp_diag = {"ms_per_step_without_collectives": round(1e3 * dt0 / a.steps, 4),
                    "exposed_communication_ms": round(1e3 * (dt - dt0) / a.steps, 4),
-                   "buckets_bytes": [4 * eng.n_dec, 4 * (eng.n_bot - eng.n_dec), 4 * (eng.flat_g.numel() - eng.n_bot)]}
+                   "buckets_bytes": [4 * eng.n_dec, 4 * (eng.n_bot - eng.n_dec), 4 * (eng.flat_g.numel() - eng.n_bot)],
+                   "ranks": world, "backend": torch.distributed.get_backend(),
+                   "what": "the step with its collectives (timed as `ms_per_step`) against the same step with every collective "
+                           "switched off afterwards" + ("; ONE-rank RCCL group (SX_DP_FORCE=1)" if forced else "")}
     line = {
         "metric": "train samples/s, cond. U-Net 128x64 grid (full training step)", "value": round(value, 2),
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -544,7 +556,7 @@ def main():
                                "gpu_samples_per_s": round(g_v, 1), "cpu_samples_per_s": round(c_v, 1), "cpu_threads": threads,
                                "loss_gpu": g_loss, "loss_cpu": c_loss}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

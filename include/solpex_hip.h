@@ -150,7 +150,10 @@ int sx_conv_wgrad(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int 
  * reference.  The split-K slabs live in a static device array of SX_WGRAD_STATIC_BYTES that every GPU the library runs
  * on holds until the process ends; the call allocates and frees nothing.  Problems whose slabs
  * (sx_conv_wgrad_workspace_bytes) exceed that size are rejected with SX_ERR_UNSUPPORTED.  All calls on one GPU share
- * the array: calls that overlap on one GPU (different streams or threads) race. */
+ * the array: calls that overlap on one GPU (different streams or threads) race.
+ * Under HIP graph capture: the FIRST call per device takes the array's address (hipGetSymbolAddress) and the first call per
+ * kernel instantiation sets a function attribute (and, in fp32, asks the occupancy calculator) -- host calls that must not
+ * happen for the first time inside a capture.  Run one call per (shape, dtype) on each device outside capture first. */
 #define SX_WGRAD_STATIC_BYTES (32u << 20)
 int sx_conv_wgrad_static(int dtype, int mode, int B, int H, int W, int Ca, int Cb, int Ca_out, int Cb_out,
                          const void* P, int p_ld, const void* Q, int q_ld, int Hq, int Wq,
@@ -306,14 +309,24 @@ int sx_loss_ev_l1(int dtype, int B, int C, int H, int W, const void* pred, int p
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (train.py:82,226-233): grad-norm, clip_grad_norm_, AdamW over one flat fp32 arena.
  * --------------------------------------------------------------------------------------------- */
-int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
-/* The first half of sx_grad_sumsq alone (deterministic block partials left on the device; returns their count, >= 1):
- * follow it, on the same stream, with sx_adamw_step(gnorm_sq = NULL, max_norm > 0, same g and n), whose blocks add the
- * partials themselves in a fixed order -- clip_grad_norm_ + AdamW in two launches instead of three. */
-int sx_grad_sumsq_partial(const float* g, int64_t n, void* stream);
+/* The gradient norm is summed in a fixed order (bit-identical on every data-parallel rank) through block partials that
+ * live in CALLER-OWNED device memory: `parts` = SX_SUMSQ_PARTS floats.  The library keeps no mutable device state for
+ * this, so steps that overlap on one GPU (two engines, two streams) cannot see each other's norm.
+ * sx_grad_sumsq: out[0] += sum g^2 (caller zeroes out).
+ * sx_grad_sumsq_partial: its first half alone; returns the number of partials written (>= 1) or a negative status.
+ * sx_adamw_step: gnorm_sq != NULL clips with that sum of squares; gnorm_sq == NULL never clips, whatever max_norm says.
+ * sx_adamw_step_fused: clip_grad_norm_ + AdamW in two launches instead of three -- every block of the AdamW launch adds up
+ *   the partials of sx_grad_sumsq_partial(g, n, parts) (same stream, just before) itself; nparts must be that call's
+ *   return value (checked against n). */
+#define SX_SUMSQ_PARTS 256
+int sx_grad_sumsq(const float* g, int64_t n, float* out, float* parts, void* stream);
+int sx_grad_sumsq_partial(const float* g, int64_t n, float* parts, void* stream);
 int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float max_norm,
                   const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream);
+int sx_adamw_step_fused(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float max_norm,
+                        const float* parts, int nparts, float grad_mul, float* gnorm_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched inverse problems through the frozen network (scripts/eval_inverse_cycle_conditional_unet.py):

@@ -221,10 +221,12 @@ def test_cfg5_full_grid_train_step_against_oracle(cfg5_case, dtype, tol_loss, to
                    "gnorm": float(eng.gnorm), "gnorm_oracle": gnorm_ref}, f)
 
 
-def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode):
+def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode, monkeypatch):
     """The same step with the Sobel-L1 term switched off (its sign() turns last-bit prediction differences into O(1e-3)
     gradient differences): what is left is the arithmetic of the convolutions themselves -- the figure for the 1e-4 bar at
-    the longest contraction of the envelope (K = 512 x 9), split-bf16 and exact fp32 MFMA."""
+    the longest contraction of the envelope (K = 512 x 9).  Networks this wide run exact fp32 MFMA whatever the process-wide
+    mode (unet_plan.hip: plan_wants_exact) because split-bf16 arithmetic measured 4.1e-4 here; SX_FP32_WIDE_SPLIT=1 keeps
+    them on the split kernels, and that figure is recorded (not held to the bar) beside the default's."""
     import json
     from oracle import unet_ref, loss_ref
     from unet_amd.models import UNet
@@ -234,19 +236,28 @@ def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     loss_r = loss_ref.masked_weighted_loss(unet_ref.unet_forward(sdr, cfg, bt["x"], None), bt["y"], bt["mask"], w=w, **opts)
     loss_r.backward()
-    model = UNet(in_ch=10, out_ch=4, base=64, P=0, depth=3)
-    model.load_state_dict(sd)
-    model = model.cuda().train()
-    eng = TrainEngine(model, dtype=torch.float32, lr=LR, weight_decay=WD, clip_grad=CLIP, w_map=w, loss_opts=opts)
-    out = eng.train_step(*(bt[k].cuda() for k in ("x", "y", "mask")), None, lam_grad=0.0)
-    torch.cuda.synchronize()
-    assert abs(float(out[0]) - float(loss_r)) < 1e-5 * abs(float(loss_r))
     gmax = max(float(v.grad.norm()) for v in sdr.values())
-    worst = (0.0, "")
-    for k, q in model.named_parameters():
-        gd, rd = q.grad.detach().cpu().double().reshape(-1), sdr[k].grad.double().reshape(-1)
-        worst = max(worst, (float((gd - rd).norm()) / max(float(rd.norm()), 1e-3 * gmax), k))
-    print(f"[cfg5 256x128 fp32 {fp32_mode}, smooth loss] worst gradient {worst}")
+
+    def worst_gradient():
+        model = UNet(in_ch=10, out_ch=4, base=64, P=0, depth=3)
+        model.load_state_dict(sd)
+        model = model.cuda().train()
+        eng = TrainEngine(model, dtype=torch.float32, lr=LR, weight_decay=WD, clip_grad=CLIP, w_map=w, loss_opts=opts)
+        out = eng.train_step(*(bt[k].cuda() for k in ("x", "y", "mask")), None, lam_grad=0.0)
+        torch.cuda.synchronize()
+        assert abs(float(out[0]) - float(loss_r)) < 1e-5 * abs(float(loss_r))
+        worst = (0.0, "")
+        for k, q in model.named_parameters():
+            gd, rd = q.grad.detach().cpu().double().reshape(-1), sdr[k].grad.double().reshape(-1)
+            worst = max(worst, (float((gd - rd).norm()) / max(float(rd.norm()), 1e-3 * gmax), k))
+        return worst
+    res = {"default": worst_gradient()}
+    if fp32_mode == "split":
+        monkeypatch.setenv("SX_FP32_WIDE_SPLIT", "1")
+        res["forced_split"] = worst_gradient()
+        monkeypatch.delenv("SX_FP32_WIDE_SPLIT")
+        assert res["forced_split"][0] < 1e-3
+    print(f"[cfg5 256x128 fp32, process-wide mode {fp32_mode}, smooth loss] worst gradient {res}")
     with open(f"gpurun_out/cfg5_parity_smooth_{fp32_mode}.json", "w") as f:
-        json.dump({"worst_gradient_rel": worst[0], "worst_gradient": worst[1]}, f)
-    assert worst[0] < 1e-4, worst
+        json.dump({k: {"worst_gradient_rel": v[0], "tensor": v[1]} for k, v in res.items()}, f)
+    assert res["default"][0] < 1e-4, res

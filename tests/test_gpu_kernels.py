@@ -646,11 +646,12 @@ def test_adamw_clip_matches_golden(L, golden):
     v = torch.zeros_like(flat_p)
     ss = torch.zeros(2, device="cuda")       # two sum-of-squares slots: each step's kernel clears the next step's slot
     gn = torch.zeros(1, device="cuda")
+    parts = torch.zeros(256, device="cuda")  # SX_SUMSQ_PARTS: caller-owned block partials of the norm
     lib = L.lib()
     for step in range(3):
         flat_g = torch.cat([t(g[f"g{step}_{i}"]).reshape(-1) for i in range(n)]).cuda()
         cur, nxt = ss[step & 1:], ss[(step + 1) & 1:]
-        L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(cur), L.stream_ptr()))
+        L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(cur), L.ptr(parts), L.stream_ptr()))
         L.check(lib.sx_adamw_step(L.ptr(flat_p), L.ptr(flat_g), L.ptr(m), L.ptr(v), flat_p.numel(), float(g["lr"]), 0.9, 0.999,
                                   1e-8, float(g["wd"]), step + 1, float(g["clip"]), L.ptr(cur), 1.0, L.ptr(gn), L.ptr(nxt),
                                   L.stream_ptr()))
@@ -660,6 +661,30 @@ def test_adamw_clip_matches_golden(L, golden):
         for i in range(n):
             assert max_err(flat_p[off:off + sizes[i]].cpu(), g[f"p{step + 1}_{i}"].reshape(-1)) < 2e-6
             off += sizes[i]
+    # the two-launch form (partials + an AdamW launch that totals them itself) is bit-identical to the three-launch form,
+    # rejects partials that belong to another size, and sx_adamw_step without a norm never clips
+    p_a, p_b = flat_p.clone(), flat_p.clone()
+    m_a, m_b, v_a, v_b = m.clone(), m.clone(), v.clone(), v.clone()
+    ss.zero_()
+    L.check(lib.sx_grad_sumsq(L.ptr(flat_g), flat_g.numel(), L.ptr(ss), L.ptr(parts), L.stream_ptr()))
+    L.check(lib.sx_adamw_step(L.ptr(p_a), L.ptr(flat_g), L.ptr(m_a), L.ptr(v_a), p_a.numel(), 1e-3, 0.9, 0.999, 1e-8, 1e-4, 4,
+                              float(g["clip"]), L.ptr(ss), 1.0, None, None, L.stream_ptr()))
+    parts2 = torch.zeros(256, device="cuda")
+    npart = lib.sx_grad_sumsq_partial(L.ptr(flat_g), flat_g.numel(), L.ptr(parts2), L.stream_ptr())
+    assert npart >= 1
+    L.check(lib.sx_adamw_step_fused(L.ptr(p_b), L.ptr(flat_g), L.ptr(m_b), L.ptr(v_b), p_b.numel(), 1e-3, 0.9, 0.999, 1e-8, 1e-4, 4,
+                                    float(g["clip"]), L.ptr(parts2), npart, 1.0, L.ptr(gn), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b)
+    with pytest.raises(ValueError):
+        L.check(lib.sx_adamw_step_fused(L.ptr(p_b), L.ptr(flat_g), L.ptr(m_b), L.ptr(v_b), p_b.numel(), 1e-3, 0.9, 0.999, 1e-8, 1e-4,
+                                        5, float(g["clip"]), L.ptr(parts2), npart + 1, 1.0, None, L.stream_ptr()))
+    p_c, m_c, v_c = flat_p.clone(), m.clone(), v.clone()
+    big = flat_g * 1e3                       # far above the clip threshold
+    L.check(lib.sx_adamw_step(L.ptr(p_c), L.ptr(big), L.ptr(m_c), L.ptr(v_c), p_c.numel(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1,
+                              float(g["clip"]), None, 1.0, None, None, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(m_c, 0.9 * m + 0.1 * big, rtol=1e-6, atol=0)          # unclipped gradient went into the moment
 
 
 def test_fp32_split_arithmetic_error_against_fp64(L, fp32_mode):

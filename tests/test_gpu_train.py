@@ -322,3 +322,50 @@ def test_optimizer_skips_parameters_without_gradients():
     opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
     eng.export_opt_state(opt)
     assert m.z_proj.weight not in opt.state and m.film_bot.net[0].weight in opt.state
+
+
+def test_film_generators_that_join_late_get_their_own_adam_step_count():
+    """torch.optim.AdamW counts steps per parameter and holds no state for parameters that never had a gradient
+    (solpex/train.py:82,226-233): after unconditioned steps, the FiLM generators' FIRST step must be bias-corrected as step 1
+    (|update| = lr for every element with a gradient), and the exported optimizer state must say so."""
+    from unet_amd.models import UNet
+    from unet_amd.train import TrainEngine
+    from unet_amd.synth import make_batch
+    torch.manual_seed(0)
+    model = UNet(in_ch=1, out_ch=8, base=8, P=5, film_hidden=16, depth=2).cuda().train()
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if "film" in n and ".net.2." in n:
+                q.normal_(0.0, 0.05)
+    bt = make_batch(4, 16, 8, seed=3, jitter_masks=True)
+    x, y, m, p = (bt[k].cuda() for k in ("x", "y", "mask", "params"))
+    lr = 1e-3
+    eng = TrainEngine(model, dtype=torch.float32, lr=lr, weight_decay=0.0, clip_grad=1.0, loss_opts=dict(lam_grad=0.0, lam_w=0.0))
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    for _ in range(3):
+        eng.train_step(x, y, m, None, lam_grad=0.0)             # unconditioned: no FiLM gradients, no FiLM state
+    eng.export_opt_state(opt)
+    film = [q for n, q in model.named_parameters() if n.startswith("film_")]
+    conv = dict(model.named_parameters())["encoders.0.net.0.weight"]
+    assert all(q not in opt.state for q in film) and float(opt.state[conv]["step"]) == 3.0
+    before = {n: q.detach().clone() for n, q in model.named_parameters() if n.startswith("film_")}
+    eng.train_step(x, y, m, p, lam_grad=0.0)
+    torch.cuda.synchronize()
+    checked = 0
+    for n, q in model.named_parameters():
+        if not n.startswith("film_"):
+            continue
+        g = q.grad.detach()
+        big = g.abs() > 0.1 * g.abs().max().clamp_min(1e-30)        # (Adam's eps = 1e-8 shortens the step of tiny gradients)
+        if int(big.sum()) == 0:
+            continue
+        step = (q.detach() - before[n]).abs()[big] / lr
+        assert float((step - 1.0).abs().max()) < 5e-2, (n, float(step.min()), float(step.max()))     # step 4 would give 0.56
+        checked += 1
+    assert checked >= 4
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    eng.export_opt_state(opt)
+    assert all(float(opt.state[q]["step"]) == 1.0 for q in film) and float(opt.state[conv]["step"]) == 4.0
+    eng2 = TrainEngine(model, dtype=torch.float32, lr=lr, weight_decay=0.0, clip_grad=1.0, loss_opts=dict(lam_grad=0.0, lam_w=0.0))
+    eng2.import_opt_state(opt)
+    assert (eng2.step_count, eng2.film_steps) == (4, 1)

@@ -25,12 +25,20 @@ def _both(L, dtype, mode, B, H, W, Cin, Cout, seed):
     got = ref.clone()
     L.check(lib.sx_conv_wgrad(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
                               L.ptr(ref), 1, L.ptr(ws), nb, L.stream_ptr()), "sx_conv_wgrad")
+    # warm-up call: the first call per device / kernel instantiation takes the symbol address and sets function attributes
+    # (documented in solpex_hip.h); what must allocate nothing is every call after it
+    warm = got.clone()
+    L.check(lib.sx_conv_wgrad_static(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
+                                     L.ptr(warm), 1, L.stream_ptr()), "sx_conv_wgrad_static")
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
+    free_before = torch.cuda.mem_get_info()[0]          # the driver's view: sees a raw hipMalloc that torch's counter cannot
     L.check(lib.sx_conv_wgrad_static(dtype, mode, B, H, W, Cout, Cin, Cout, Cin, L.ptr(dyd), Cout, L.ptr(xd), Cin, H, W,
                                      L.ptr(got), 1, L.stream_ptr()), "sx_conv_wgrad_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] >= free_before, "sx_conv_wgrad_static took device memory"
+    assert torch.equal(warm, got)
     assert torch.isfinite(ref).all() and float(ref.abs().max()) > 1.0
     return ref.cpu(), got.cpu()
 

@@ -77,8 +77,9 @@ SIGNATURES = {
     "sx_norm_apply": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sx_masked_err_sums": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sx_loss_ev_l1": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _f, _p]),
-    "sx_grad_sumsq": (_i, [_p, _l, _p, _p]),
-    "sx_grad_sumsq_partial": (_i, [_p, _l, _p]),
+    "sx_grad_sumsq": (_i, [_p, _l, _p, _p, _p]),
+    "sx_grad_sumsq_partial": (_i, [_p, _l, _p, _p]),
+    "sx_adamw_step_fused": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p, _i, _f, _p, _p]),
     "sx_conv3_shortcut_forward": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
     "sx_conv3_shortcut_dgrad": (_i, [_i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
     "sx_inverse_fit": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _p]),

@@ -37,7 +37,11 @@ int env_int(const char* name, int dflt) {
 
 // fp32 arithmetic of the convolution kernels: 1 = split-bf16 (three bf16 MFMAs per product block), 0 = exact fp32 MFMA
 static std::atomic<int> g_fp32_split{-1};
+static thread_local int t_fp32_exact_scope = 0;       // > 0: inside a network-level call that asked for exact arithmetic
+Fp32ExactScope::Fp32ExactScope(bool on) : on_(on) { if (on_) ++t_fp32_exact_scope; }
+Fp32ExactScope::~Fp32ExactScope() { if (on_) --t_fp32_exact_scope; }
 int fp32_split() {
+  if (t_fp32_exact_scope > 0) return 0;
   int v = g_fp32_split.load(std::memory_order_relaxed);
   if (v < 0) {
     v = env_int("SX_FP32_EXACT", 0) ? 0 : 1;

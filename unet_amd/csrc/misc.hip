@@ -260,6 +260,10 @@ extern "C" int sx_maxpool2_backward_add(int dtype, int B, int H, int W, int C, c
 extern "C" int sx_maxpool2_backward_add_idx(int dtype, int B, int H, int W, int C, const void* pool_idx, int idx_ld, const void* dp,
                                             int dp_ld, const void* dskip, int ds_ld, void* dx, int dx_ld, void* stream) {
   SX_REQUIRE(pool_idx && dp && dx, "sx_maxpool2_backward_add_idx: null pointer");
+  SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_maxpool2_backward_add_idx: bad dtype %d", dtype);
+  SX_REQUIRE(idx_ld >= C && dp_ld >= C && dx_ld >= C && (!dskip || ds_ld >= C),
+             "sx_maxpool2_backward_add_idx: a leading dimension is smaller than C=%d (idx %d, dp %d, dskip %d, dx %d)", C, idx_ld, dp_ld,
+             ds_ld, dx_ld);
   if (C % 8 || idx_ld % 8 || dp_ld % 8 || dx_ld % 8 || (dskip && ds_ld % 8) || (H & 1) || (W & 1) || H < 2 || W < 2 ||
       ((uintptr_t)pool_idx % 8)) {
     set_error("sx_maxpool2_backward_add_idx: need C %% 8 == 0, even H and W, 8-byte aligned positions");

@@ -6,14 +6,14 @@
 
 namespace sx {
 
-// Block partials of sx_grad_sumsq (one copy per device; referenced by the kernels only).  The norm must come out bit-identical
-// on every data-parallel rank -- it sets the clip factor, and ranks whose clip factors differ in the last bit drift apart --
-// so the partials are summed in a fixed order by a second one-block launch instead of racing on an atomic.
-static __device__ float g_sumsq_part[256];
+// Block partials of the gradient norm live in CALLER-OWNED memory (`parts`, SX_SUMSQ_PARTS floats: the library keeps no mutable
+// device state, so steps that overlap on one GPU -- two engines, two streams -- cannot clip with each other's norm).  The norm
+// must come out bit-identical on every data-parallel rank -- it sets the clip factor, and ranks whose clip factors differ in
+// the last bit drift apart -- so the partials are summed in a fixed order instead of racing on an atomic.
 
 // fixed-order sum of the block partials; every thread of the calling block gets the total (same bits in every block)
-__device__ __forceinline__ float sumsq_total(int nparts) {
-  float v[1] = {(int)threadIdx.x < nparts ? g_sumsq_part[threadIdx.x] : 0.f};
+__device__ __forceinline__ float sumsq_total(const float* __restrict__ parts, int nparts) {
+  float v[1] = {(int)threadIdx.x < nparts ? parts[threadIdx.x] : 0.f};
   __shared__ float red[4];
   __shared__ float tot;
   block_sum<1>(v, red);
@@ -22,12 +22,12 @@ __device__ __forceinline__ float sumsq_total(int nparts) {
   return tot;
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(int nparts, float* __restrict__ out) {
-  const float t = sumsq_total(nparts);
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ parts, int nparts, float* __restrict__ out) {
+  const float t = sumsq_total(parts, nparts);
   if (threadIdx.x == 0) out[0] += t;
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ parts) {
   float v[1] = {0.f};
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[n4 * 4 + threadIdx.x]; v[0] += x * x; }
   __shared__ float red[4];
   block_sum<1>(v, red);
-  if (threadIdx.x == 0) g_sumsq_part[blockIdx.x] = v[0];
+  if (threadIdx.x == 0) parts[blockIdx.x] = v[0];
 }
 
 struct AdamArgs {
@@ -46,7 +46,7 @@ struct AdamArgs {
   float max_norm; const float* gnorm_sq; float grad_mul;
   float* gnorm_out;
   float* clear_after;
-  int fused_parts;      // > 0: the norm comes from the block partials sx_grad_sumsq_partial left on this device (no gnorm_sq)
+  const float* parts; int fused_parts;      // > 0: the norm comes from these block partials of sx_grad_sumsq_partial (no gnorm_sq)
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float gmul) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   if (a.gnorm_sq || a.fused_parts > 0) {
     // fused: every block adds the partials itself, in the same fixed order -> the same clip factor everywhere, and no
     // one-block launch in between
-    const float ss = a.fused_parts > 0 ? sumsq_total(a.fused_parts) : a.gnorm_sq[0];
+    const float ss = a.fused_parts > 0 ? sumsq_total(a.parts, a.fused_parts) : a.gnorm_sq[0];
     const float norm = sqrtf(ss) * fabsf(a.grad_mul);
     if (a.max_norm > 0.f) gmul *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
     if (a.gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) a.gnorm_out[0] = norm;
@@ -91,42 +91,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 using namespace sx;
 
-// out[0] += sum g^2 (caller zeroes out).  Deterministic: fixed grid, fixed-order sums.  Calls that overlap on one device
-// (different streams) race on the partials scratch.
-static int sumsq_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 256)); }
+// Deterministic: fixed grid, fixed-order sums.
+static int sumsq_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), SX_SUMSQ_PARTS)); }
 
-// sx_grad_sumsq's first half alone: leaves the block partials on the device for sx_adamw_step(gnorm_sq = NULL, max_norm > 0,
-// same n), whose blocks add them up themselves.  Returns the number of partials (>= 1) or a negative status.
-extern "C" int sx_grad_sumsq_partial(const float* g, int64_t n, void* stream) {
-  SX_REQUIRE(g && n > 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq_partial: bad arguments");
+// Block partials of sum g^2 into parts[0 .. count) (caller-owned, SX_SUMSQ_PARTS floats); returns count (>= 1) or a negative
+// status.  sx_adamw_step_fused(parts, count) adds them up itself.
+extern "C" int sx_grad_sumsq_partial(const float* g, int64_t n, float* parts, void* stream) {
+  SX_REQUIRE(g && parts && n > 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq_partial: bad arguments");
   const int blocks = sumsq_blocks(n);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, parts);
   SX_LAUNCH_CHECK("grad_sumsq");
   return blocks;
 }
 
-extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
-  SX_REQUIRE(g && out && n >= 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq: bad arguments");
+// out[0] += sum g^2 (caller zeroes out); parts: SX_SUMSQ_PARTS floats of caller-owned scratch.
+extern "C" int sx_grad_sumsq(const float* g, int64_t n, float* out, float* parts, void* stream) {
+  SX_REQUIRE(g && out && parts && n >= 0 && ((uintptr_t)g % 16) == 0, "sx_grad_sumsq: bad arguments");
   if (n == 0) return SX_OK;
   const int blocks = sumsq_blocks(n);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, parts);
   SX_LAUNCH_CHECK("grad_sumsq");
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, blocks, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)parts, blocks, out);
   SX_LAUNCH_CHECK("grad_sumsq_final");
   return SX_OK;
 }
 
-// One AdamW step over a flat arena.  step is the 1-based step count.  If gnorm_sq != NULL the
-// gradients are first scaled by min(1, max_norm / (sqrt(gnorm_sq) * |grad_mul| + 1e-6)) (max_norm <= 0:
-// no clipping); grad_mul is a plain multiplier (e.g. 1/world_size, or 1/loss_scale).
-// gnorm_out (nullable) receives the pre-clip norm.  clear_after (nullable, must not alias gnorm_sq) is set to 0 by
-// the kernel: callers that alternate between two sum-of-squares slots get the next step's slot zeroed for free.
-extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, float max_norm,
-                             const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream) {
-  SX_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "sx_adamw_step: bad arguments");
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float max_norm, const float* gnorm_sq, const float* parts, int nparts,
+                        float grad_mul, float* gnorm_out, float* clear_after, void* stream, const char* who) {
+  SX_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "%s: bad arguments", who);
   SX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
-             "sx_adamw_step: arenas must be 16-byte aligned");
+             "%s: arenas must be 16-byte aligned", who);
   if (n == 0) return SX_OK;
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
@@ -134,11 +129,34 @@ extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.max_norm = max_norm; a.gnorm_sq = gnorm_sq; a.grad_mul = grad_mul; a.gnorm_out = gnorm_out; a.clear_after = clear_after;
-  // gnorm_sq == NULL with clipping on: the partials of sx_grad_sumsq_partial(g, n) (same stream, same device, just before)
-  a.fused_parts = (!gnorm_sq && max_norm > 0.f) ? sumsq_blocks(n) : 0;
-  SX_REQUIRE(!clear_after || clear_after != gnorm_sq, "sx_adamw_step: clear_after must not alias gnorm_sq");
+  a.parts = parts; a.fused_parts = nparts;
+  SX_REQUIRE(!clear_after || clear_after != gnorm_sq, "%s: clear_after must not alias gnorm_sq", who);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n, 1024), 2048));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   SX_LAUNCH_CHECK("adamw_step");
   return SX_OK;
+}
+
+// One AdamW step over a flat arena.  step is the 1-based step count.  If gnorm_sq != NULL the
+// gradients are first scaled by min(1, max_norm / (sqrt(gnorm_sq) * |grad_mul| + 1e-6)) (max_norm <= 0:
+// no clipping); gnorm_sq == NULL: no clipping, whatever max_norm says.  grad_mul is a plain multiplier (e.g. 1/world_size,
+// or 1/loss_scale).  gnorm_out (nullable) receives the pre-clip norm.  clear_after (nullable, must not alias gnorm_sq) is
+// set to 0 by the kernel: callers that alternate between two sum-of-squares slots get the next step's slot zeroed for free.
+extern "C" int sx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float max_norm,
+                             const float* gnorm_sq, float grad_mul, float* gnorm_out, float* clear_after, void* stream) {
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, gnorm_sq, nullptr, 0, grad_mul, gnorm_out,
+                      clear_after, stream, "sx_adamw_step");
+}
+
+// The same step with clip_grad_norm_ taken from the block partials of sx_grad_sumsq_partial(g, n, parts) (same stream, just
+// before): every block adds them up itself, in the same fixed order -- clip + AdamW in two launches instead of three.
+// nparts must be what that call returned for this n.
+extern "C" int sx_adamw_step_fused(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int step, float max_norm,
+                                   const float* parts, int nparts, float grad_mul, float* gnorm_out, void* stream) {
+  SX_REQUIRE(parts && n > 0 && nparts == sumsq_blocks(n), "sx_adamw_step_fused: %d partials do not belong to %lld values (expected %d)",
+             nparts, (long long)n, n > 0 ? sumsq_blocks(n) : 0);
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, nullptr, parts, nparts, grad_mul, gnorm_out,
+                      nullptr, stream, "sx_adamw_step_fused");
 }

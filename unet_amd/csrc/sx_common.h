@@ -158,6 +158,16 @@ int env_int(const char* name, int dflt);
 // 1: fp32 convolutions and weight gradients run as three bf16 MFMAs on split operands (default; conv_x3.hip); 0: exact
 // fp32 MFMA (SX_FP32_EXACT=1 or sx_set_fp32_exact).  The packed fp32 weights differ between the two: repack after a switch.
 int fp32_split();
+// While alive on this thread, fp32_split() answers "exact" whatever the process-wide mode is: the whole-network entry points
+// (unet_plan.hip) use it for architectures where split arithmetic was measured outside the 1e-4 contract.
+struct Fp32ExactScope {
+  explicit Fp32ExactScope(bool on);
+  ~Fp32ExactScope();
+  Fp32ExactScope(const Fp32ExactScope&) = delete;
+  Fp32ExactScope& operator=(const Fp32ExactScope&) = delete;
+ private:
+  bool on_;
+};
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -412,7 +412,10 @@ def rank_share(global_batch, rank, world, pad):
     """Rank `rank`'s rows of one GLOBAL batch of positions (a LongTensor): the batch is cut into `world` equal consecutive
     shares; a short last batch is padded with `pad` (the position of an all-zero-mask sample, which adds nothing to any
     masked sum), so every rank sees the same number of rows and of batches.  Concatenating the shares of ranks 0..world-1
-    gives the global batch back (plus padding): DP-N at per-rank batch b reproduces the single-process run at batch N*b."""
+    gives the global batch back (plus padding): DP-N at per-rank batch b sees, step for step, the global batches a run at
+    batch N*b would see FROM THE SAME PERMUTATION.  (The world == 1 loader draws its permutation from torch's global RNG like
+    the reference's DataLoader; world > 1 loaders draw from a generator seeded by rank 0 -- equal batch contents need the
+    serial run to be given that generator, otherwise the two runs are equivalent only up to the order of the epoch.)"""
     g = int(global_batch.numel())
     per = (g + world - 1) // world
     mine = global_batch[rank * per:(rank + 1) * per]
@@ -430,6 +433,8 @@ class ResidentLoader:
     Yields the same dict (`x`, `y`, `mask`, `params`, `idx`) with the same values and the same batch order as the
     host loader for a given torch seed; tensors are already on `device` (`idx` stays a host LongTensor).
     """
+
+    _warned_unsynced = False
 
     def __init__(self, subset, batch_size, shuffle, device, drop_last=False, chunk=256, rank=None, world=None):
         """Under data parallelism (`rank` / `world`, default: the process group's) `batch_size` is the PER-RANK batch: the
@@ -494,6 +499,14 @@ class ResidentLoader:
         seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
         if sxdist.is_active() and sxdist.world_size() == self.world:
             seed = sxdist.broadcast0(seed, self.device)
+        elif not ResidentLoader._warned_unsynced:
+            # explicit rank= / world= without a matching process group: nothing to agree on a seed through.  Correct only if
+            # every rank's global RNG is in the same state (same torch.manual_seed, same draws so far)
+            import warnings
+            ResidentLoader._warned_unsynced = True
+            warnings.warn(f"ResidentLoader: world={self.world} but no process group of that size is active: the epoch permutation "
+                          "is seeded from this process's global RNG alone -- ranks whose RNG states differ will duplicate or drop "
+                          "samples.  Seed every rank identically, or initialise torch.distributed first.")
         self._gen.manual_seed(int(seed))
 
     def _gather(self, src, n_src, row, pos, nb, dst, dst_stride):

@@ -207,6 +207,7 @@ class _Trainer:
         self.step_count = 0
         self._ss = torch.zeros(2, dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
+        self._parts = torch.zeros(256, dtype=torch.float32, device=device)          # SX_SUMSQ_PARTS: norm partials of this trainer
         self.log = torch.zeros(1024, 4, dtype=torch.float32, device=device)
         self.nlog = 0
         self.sizes = []
@@ -228,7 +229,7 @@ class _Trainer:
         self.step_count += 1
         n = self.flat_p.numel()
         cur, nxt = self._ss[self.step_count & 1:], self._ss[(self.step_count + 1) & 1:]
-        L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(cur), L.stream_ptr()), "sx_grad_sumsq")
+        L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(cur), L.ptr(self._parts), L.stream_ptr()), "sx_grad_sumsq")
         L.check(lib.sx_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n, self.lr,
                                   0.9, 0.999, 1e-8, self.wd, self.step_count, 1.0, L.ptr(cur), 1.0, L.ptr(self.gnorm),
                                   L.ptr(nxt), L.stream_ptr()), "sx_adamw_step")

@@ -104,6 +104,8 @@ class TrainEngine:
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_count = 0
+        self.film_steps = 0        # optimizer steps that included the FiLM generators (torch's AdamW counts steps per parameter)
+        self._ss = torch.zeros(1, dtype=torch.float32, device=self.device)
         named = dict(model.named_parameters())
         self._const_grads = {n: torch.zeros_like(t) for n, t in const.items()}      # scratch the kernels may write
         self.params = [named[n] if n in named else const[n] for n in names]
@@ -124,6 +126,7 @@ class TrainEngine:
             self._ev_table = norm_table(norm, self.cfg["out_ch"])
         self._sessions = {}
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.sumsq_parts = torch.zeros(256, dtype=torch.float32, device=self.device)     # SX_SUMSQ_PARTS: this engine's norm partials
         self.accum = 0
         # device-side per-batch log rows [loss, sum|p-t|*m, px (global under DP), px (local)], read once per epoch
         self.log = torch.zeros(4096, 4, dtype=torch.float32, device=self.device)
@@ -256,13 +259,36 @@ class TrainEngine:
         self.step_count += 1
         n = self.n_kernel if n is None else int(n)
         use_clip = bool(self.clip and self.clip > 0)
-        if use_clip:
-            # deterministic block partials of sum g^2; the AdamW blocks add them up themselves (no one-block launch between)
-            L.check(lib.sx_grad_sumsq_partial(L.ptr(self.flat_g), n, L.stream_ptr()), "sx_grad_sumsq_partial")
-        L.check(lib.sx_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n,
-                                  float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps, self.wd,
-                                  self.step_count, float(self.clip) if use_clip else 0.0, None,
-                                  1.0, L.ptr(self.gnorm) if use_clip else None, None, L.stream_ptr()), "sx_adamw_step")
+        lr_now = float(self.lr if lr is None else lr)
+        with_film = n > self.n_film
+        if with_film:
+            self.film_steps += 1
+        if with_film and self.film_steps != self.step_count:
+            # The generators joined late (unconditioned steps came first): torch.optim.AdamW keeps a step count per parameter,
+            # so their bias correction runs on their own count.  One norm over everything, two AdamW launches.
+            gsq = None
+            if use_clip:
+                self._ss.zero_()
+                L.check(lib.sx_grad_sumsq(L.ptr(self.flat_g), n, L.ptr(self._ss), L.ptr(self.sumsq_parts), L.stream_ptr()), "sx_grad_sumsq")
+                gsq = L.ptr(self._ss)
+            for lo, hi, stp in ((0, self.n_film, self.step_count), (self.n_film, n, self.film_steps)):
+                L.check(lib.sx_adamw_step(L.ptr(self.flat_p[lo:hi]), L.ptr(self.flat_g[lo:hi]), L.ptr(self.flat_m[lo:hi]),
+                                          L.ptr(self.flat_v[lo:hi]), hi - lo, lr_now, self.betas[0], self.betas[1], self.eps, self.wd,
+                                          stp, float(self.clip) if use_clip else 0.0, gsq, 1.0,
+                                          L.ptr(self.gnorm) if use_clip else None, None, L.stream_ptr()), "sx_adamw_step")
+        elif use_clip:
+            # deterministic block partials of sum g^2 (in this engine's own scratch); the AdamW blocks add them up themselves
+            # (no one-block launch between)
+            nparts = lib.sx_grad_sumsq_partial(L.ptr(self.flat_g), n, L.ptr(self.sumsq_parts), L.stream_ptr())
+            L.check(min(nparts, 0), "sx_grad_sumsq_partial")
+            L.check(lib.sx_adamw_step_fused(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n, lr_now,
+                                            self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, float(self.clip),
+                                            L.ptr(self.sumsq_parts), nparts, 1.0, L.ptr(self.gnorm), L.stream_ptr()),
+                    "sx_adamw_step_fused")
+        else:
+            L.check(lib.sx_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.flat_m), L.ptr(self.flat_v), n, lr_now,
+                                      self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 0.0, None, 1.0, None, None,
+                                      L.stream_ptr()), "sx_adamw_step")
         self.accum = 0
         self.model._wgen += 1          # the kernel wrote the parameters through raw pointers: packed-weight caches are stale
 
@@ -319,9 +345,11 @@ class TrainEngine:
         """Fill a torch.optim.AdamW's state with views of the engine's moments (checkpoint format parity)."""
         for n, p in self.model.named_parameters():
             o, k = self.slots[n]
-            if o >= self.n_kernel:           # never stepped (no gradient): the reference's optimizer holds no state for it
+            film = self.n_film <= o < self.n_kernel
+            steps = self.film_steps if film else self.step_count
+            if o >= self.n_kernel or steps == 0:      # never stepped (no gradient): the reference's optimizer holds no state for it
                 continue
-            opt.state[p] = {"step": torch.tensor(float(self.step_count)),
+            opt.state[p] = {"step": torch.tensor(float(steps)),
                             "exp_avg": self.flat_m[o:o + k].view(p.shape), "exp_avg_sq": self.flat_v[o:o + k].view(p.shape)}
 
     def import_opt_state(self, opt):
@@ -332,7 +360,10 @@ class TrainEngine:
             o, k = self.slots[n]
             self.flat_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.flat_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-            self.step_count = int(float(st["step"]))
+            if self.n_film <= o < self.n_kernel:
+                self.film_steps = int(float(st["step"]))
+            else:
+                self.step_count = int(float(st["step"]))
 
 
 def train_unet(
