@@ -42,6 +42,9 @@ Fp32ExactScope::Fp32ExactScope(bool on) : on_(on) { if (on_) ++t_fp32_exact_scop
 Fp32ExactScope::~Fp32ExactScope() { if (on_) --t_fp32_exact_scope; }
 int fp32_split() {
   if (t_fp32_exact_scope > 0) return 0;
+  return fp32_split_process();
+}
+int fp32_split_process() {
   int v = g_fp32_split.load(std::memory_order_relaxed);
   if (v < 0) {
     v = env_int("SX_FP32_EXACT", 0) ? 0 : 1;

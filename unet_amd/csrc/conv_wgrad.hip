@@ -659,15 +659,18 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
       }
     }
   }
+  // experiment knob: SX_X3_WGRAD = 0 / 1 forces exact / split arithmetic for the weight gradients alone (default: as the convolutions)
+  const int wg_force = env_int("SX_X3_WGRAD", -1);
+  const bool wsplit = wg_force < 0 ? fp32_split_process() != 0 : wg_force != 0;
   static const int x3_blocks = env_int("SX_X3_WG_BLOCKS", 512);
   // split-bf16 arithmetic, <= 48 output rows (the level-0 layers): 128-pixel tiles.  A 64-pixel tile's MFMAs (0.8 us) are
   // shorter than the HBM latency of the next tile's register prefetch, and its halo over-fetch is 1.7x against 1.4x
   static const int x3_tp = env_int("SX_X3_WG_TP", 128);
-  if (dtype == SX_F32 && fp32_split() && mode != SX_CONVT_FWD && round_up(Ca, 16) < 64 && x3_tp != 64) {
+  if (dtype == SX_F32 && wsplit && mode != SX_CONVT_FWD && round_up(Ca, 16) < 64 && x3_tp != 64) {
     SX_TRY(wgrad_geom(mode, dtype, B, H, W, a, x3_tp));
     if (a.LH * a.LW * 16 > 12 * 256 || a.TP % 32) SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));      // 4-wide grids: the halo of a 32 x 4 tile exceeds the staging slots
   }
-  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && fp32_split()) ? x3_blocks : 1024);
+  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && wsplit) ? x3_blocks : 1024);
   SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
              (long long)slab_bytes, p.ws_bytes);
   a.P = P; a.Q = Q; a.slab = (float*)slab;
@@ -676,7 +679,7 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
   a.nbf = p.nbf; a.tiles_per_split = p.tiles_per_split;
   int rc;
   if (dtype == SX_BF16) rc = p.MI == 4 ? wgrad_items<bf16, 4>(a, p, st) : wgrad_items<bf16, 2>(a, p, st);
-  else if (fp32_split()) rc = p.MI == 4 ? wgrad_items_x3<4>(a, p, st) : wgrad_items_x3<2>(a, p, st);
+  else if (wsplit) rc = p.MI == 4 ? wgrad_items_x3<4>(a, p, st) : wgrad_items_x3<2>(a, p, st);
   else rc = p.MI == 4 ? wgrad_items<float, 4>(a, p, st) : wgrad_items<float, 2>(a, p, st);
   SX_TRY(rc);
   desc->slab = (const float*)slab; desc->nsplit = p.nsplit; desc->ntaps = a.ntaps; desc->CaPad = a.CaPad; desc->CbPad = a.CbPad;

@@ -158,6 +158,10 @@ int env_int(const char* name, int dflt);
 // 1: fp32 convolutions and weight gradients run as three bf16 MFMAs on split operands (default; conv_x3.hip); 0: exact
 // fp32 MFMA (SX_FP32_EXACT=1 or sx_set_fp32_exact).  The packed fp32 weights differ between the two: repack after a switch.
 int fp32_split();
+// the process-wide mode alone, whatever scope is active: the WEIGHT GRADIENTS follow it (measured at BASELINE configs[4], full
+// grid, tools/fp32_mix.py: the split arithmetic's error comes from the forward / data-gradient convolutions alone --
+// convolutions split 3.95e-4 with exact or split weight gradients, convolutions exact 3.31e-5 with either)
+int fp32_split_process();
 // While alive on this thread, fp32_split() answers "exact" whatever the process-wide mode is: the whole-network entry points
 // (unet_plan.hip) use it for architectures where split arithmetic was measured outside the 1e-4 contract.
 struct Fp32ExactScope {
