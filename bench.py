@@ -254,8 +254,9 @@ def config5_leg(dev, L, batch=32, steps=8):
         out[name] = {"ms_per_step": round(1e3 * d, 3), "samples_per_s": round(batch / d, 1), "steps": steps,
                      "model_TFLOPs": round(116.85e9 * batch / d / 1e12, 1), "final_loss": float(eng.log[eng.nlog - 1, 0])}
         del eng, model
-    out["fp32"]["arithmetic"] = ("exact fp32 MFMA: networks whose widest layer reaches 512 channels leave the split-bf16 kernels "
-                                 "(measured 4.1e-4 worst gradient error there against the 1e-4 contract; unet_plan.hip)")
+    out["fp32"]["arithmetic"] = ("convolutions on three bf16 planes (six MFMAs per product block, fp32-grade products), weight gradients "
+                                 "on two: networks whose widest layer reaches 512 channels leave the two-plane kernels (4.1e-4 worst "
+                                 "gradient error measured there against the 1e-4 contract; unet_plan.hip)")
     out["bf16"]["mfma_frac_of_step"] = round(out["bf16"]["model_TFLOPs"] / 2500.0, 4)
     fl, secs, n, nbytes = measure_conv_roofline(batch, L.SX_BF16, reps=3, arch=ARCH_B)
     tfs = fl / secs / 1e12

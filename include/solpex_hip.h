@@ -79,6 +79,11 @@ int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c_k);
  * after a switch.  Process-wide; do not switch while calls are in flight on other threads.  No counterpart in the
  * reference (torch.backends.cudnn.allow_tf32 is the closest knob). */
 int sx_set_fp32_exact(int on);
+/* The same switch with the split form's plane count spelled out: 0 = exact fp32 MFMA, 2 = hi + lo planes (three bf16 MFMAs per
+ * product block, ~4e-6 per convolution; the default), 3 = hi + mid + lo (six MFMAs, fp32-grade products).  Any other value only
+ * queries.  Returns the previous setting.  Packed fp32 weights depend on it: repack after a switch.  Whatever the setting,
+ * the whole-network entry points run networks whose widest layer reaches 512 channels on three planes (SX_FP32_WIDE). */
+int sx_set_fp32_planes(int planes);
 int sx_pack_conv_weight(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin,
                         void* packed, void* stream);
 

@@ -23,12 +23,13 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(params=["split", "exact"])
+@pytest.fixture(params=["split", "exact", "x6"])
 def fp32_mode(request):
     """fp32 arithmetic of the convolution kernels for one test: "split" = the default (bf16 hi + lo planes, three bf16 MFMAs
-    per product block, unet_amd/csrc/conv_x3.hip), "exact" = fp32 MFMA (sx_set_fp32_exact(1)).  Restored afterwards."""
+    per product block, unet_amd/csrc/conv_x3.hip), "exact" = fp32 MFMA, "x6" = three planes / six MFMAs (sx_set_fp32_planes).
+    Restored afterwards."""
     from unet_amd import _lib
     lib = _lib.lib()
-    was = lib.sx_set_fp32_exact(1 if request.param == "exact" else 0)
+    was = lib.sx_set_fp32_planes({"exact": 0, "split": 2, "x6": 3}[request.param])
     yield request.param
-    lib.sx_set_fp32_exact(was)
+    lib.sx_set_fp32_planes(was)

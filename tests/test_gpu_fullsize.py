@@ -224,9 +224,9 @@ def test_cfg5_full_grid_train_step_against_oracle(cfg5_case, dtype, tol_loss, to
 def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode, monkeypatch):
     """The same step with the Sobel-L1 term switched off (its sign() turns last-bit prediction differences into O(1e-3)
     gradient differences): what is left is the arithmetic of the convolutions themselves -- the figure for the 1e-4 bar at
-    the longest contraction of the envelope (K = 512 x 9).  Networks this wide run exact fp32 MFMA whatever the process-wide
-    mode (unet_plan.hip: plan_wants_exact) because split-bf16 arithmetic measured 4.1e-4 here; SX_FP32_WIDE_SPLIT=1 keeps
-    them on the split kernels, and that figure is recorded (not held to the bar) beside the default's."""
+    the longest contraction of the envelope (K = 512 x 9).  Networks this wide run their convolutions on THREE bf16 planes
+    (unet_plan.hip: plan_wide_mode) because two planes measured 4.1e-4 here; SX_FP32_WIDE=2 keeps them on two planes and
+    SX_FP32_WIDE=0 sends them to the exact kernels: those figures are recorded beside the default's."""
     import json
     from oracle import unet_ref, loss_ref
     from unet_amd.models import UNet
@@ -251,12 +251,14 @@ def test_cfg5_full_grid_fp32_gradients_with_a_smooth_loss(cfg5_case, fp32_mode, 
             gd, rd = q.grad.detach().cpu().double().reshape(-1), sdr[k].grad.double().reshape(-1)
             worst = max(worst, (float((gd - rd).norm()) / max(float(rd.norm()), 1e-3 * gmax), k))
         return worst
-    res = {"default": worst_gradient()}
+    res = {"default": worst_gradient()}          # wide network: three planes unless the process-wide mode is exact
     if fp32_mode == "split":
-        monkeypatch.setenv("SX_FP32_WIDE_SPLIT", "1")
-        res["forced_split"] = worst_gradient()
-        monkeypatch.delenv("SX_FP32_WIDE_SPLIT")
-        assert res["forced_split"][0] < 1e-3
+        monkeypatch.setenv("SX_FP32_WIDE", "2")
+        res["two_planes"] = worst_gradient()
+        monkeypatch.setenv("SX_FP32_WIDE", "0")
+        res["exact_convolutions"] = worst_gradient()
+        monkeypatch.delenv("SX_FP32_WIDE")
+        assert res["two_planes"][0] < 1e-3
     print(f"[cfg5 256x128 fp32, process-wide mode {fp32_mode}, smooth loss] worst gradient {res}")
     with open(f"gpurun_out/cfg5_parity_smooth_{fp32_mode}.json", "w") as f:
         json.dump({k: {"worst_gradient_rel": v[0], "tensor": v[1]} for k, v in res.items()}, f)

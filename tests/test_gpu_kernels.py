@@ -23,14 +23,15 @@ def L():
     return _lib
 
 
-@pytest.fixture(scope="module", autouse=True, params=["split", "exact"])
+@pytest.fixture(scope="module", autouse=True, params=["split", "exact", "x6"])
 def fp32_mode(request, L):
-    """Every kernel test runs in both fp32 arithmetic modes: split-bf16 (the default: three bf16 MFMAs per product block,
-    conv_x3.hip) and exact fp32 MFMA (sx_set_fp32_exact(1)); packed fp32 weights are made after the switch.  The bf16
-    cases do not depend on it."""
-    was = L.lib().sx_set_fp32_exact(1 if request.param == "exact" else 0)
+    """Every kernel test runs in all three fp32 arithmetic modes: split-bf16 on two planes (the default: three bf16 MFMAs per
+    product block, conv_x3.hip), exact fp32 MFMA, and split-bf16 on three planes ("x6": six MFMAs, what wide networks run);
+    packed fp32 weights are made after the switch.  The bf16 cases do not depend on it."""
+    planes = {"exact": 0, "split": 2, "x6": 3}[request.param]
+    was = L.lib().sx_set_fp32_planes(planes)
     yield request.param
-    assert L.lib().sx_set_fp32_exact(was) == (1 if request.param == "exact" else 0)
+    assert L.lib().sx_set_fp32_planes(was) == planes
 
 
 def dev(x, dt=None):
@@ -712,8 +713,10 @@ def test_fp32_split_arithmetic_error_against_fp64(L, fp32_mode):
     e_y = float((from_nhwc(y, Cc).double() - ref).norm() / ref.norm())
     e_w = float((dw.cpu().double() - wref).norm() / wref.norm())
     print(f"[fp32 {fp32_mode}] conv {e_y:.2e}  wgrad {e_w:.2e}")
-    bound = 2e-6 if fp32_mode == "exact" else 2e-5
-    assert e_y < bound and e_w < bound
+    # three planes: fp32-grade convolutions; the weight gradients stay on two planes in that mode (their error does not
+    # reach the network's gradients: tools/fp32_mix.py)
+    assert e_y < (2e-5 if fp32_mode == "split" else 2e-6)
+    assert e_w < (2e-6 if fp32_mode == "exact" else 2e-5)
     if fp32_mode == "split":
         assert e_y > 5e-7          # the split kernels really ran (the exact ones sit at ~2e-7)
 

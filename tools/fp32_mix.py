@@ -22,7 +22,7 @@ sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
 loss_ref.masked_weighted_loss(unet_ref.unet_forward(sdr, cfg, bt["x"], None), bt["y"], bt["mask"], w=w, **LOSS).backward()
 gmax = max(float(v.grad.norm()) for v in sdr.values())
 big = make_batch(32, 256, 128, in_ch=10, out_ch=4, P=0, seed=3)
-os.environ["SX_FP32_WIDE_SPLIT"] = "1"
+os.environ["SX_FP32_WIDE"] = "2"
 lib = L.lib()
 for name, conv_exact, wg in (("all split", 0, -1), ("convs split, weight gradients exact", 0, 0), ("convs exact, weight gradients split", 1, 1),
                              ("all exact", 1, -1)):

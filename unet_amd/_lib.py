@@ -44,6 +44,7 @@ SIGNATURES = {
     "sx_last_error": (C.c_char_p, []),
     "sx_packed_weight_elems": (_l, [_i, _i, _i, _i]),
     "sx_set_fp32_exact": (_i, [_i]),
+    "sx_set_fp32_planes": (_i, [_i]),
     "sx_pack_conv_weight": (_i, [_i, _i, _i, _p, _i, _i, _p, _p]),
     "sx_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sx_conv_forward_gn_bwd_sums": (_i, [_i] * 7 + [_p, _i, _p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p]),

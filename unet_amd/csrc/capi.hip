@@ -35,28 +35,37 @@ int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-// fp32 arithmetic of the convolution kernels: 1 = split-bf16 (three bf16 MFMAs per product block), 0 = exact fp32 MFMA
-static std::atomic<int> g_fp32_split{-1};
-static thread_local int t_fp32_exact_scope = 0;       // > 0: inside a network-level call that asked for exact arithmetic
-Fp32ExactScope::Fp32ExactScope(bool on) : on_(on) { if (on_) ++t_fp32_exact_scope; }
-Fp32ExactScope::~Fp32ExactScope() { if (on_) --t_fp32_exact_scope; }
-int fp32_split() {
-  if (t_fp32_exact_scope > 0) return 0;
-  return fp32_split_process();
-}
-int fp32_split_process() {
-  int v = g_fp32_split.load(std::memory_order_relaxed);
+// fp32 arithmetic of the convolution kernels, process-wide: bf16 planes of the split form (2: three bf16 MFMAs per product block,
+// 3: six) or 0 = exact fp32 MFMA
+static std::atomic<int> g_fp32_planes{-1};
+static thread_local int t_fp32_wide = 0;       // inside a network-level call on a wide network: 1 = exact kernels, 3 = three planes
+Fp32WideScope::Fp32WideScope(int mode) : prev_(t_fp32_wide) { if (mode) t_fp32_wide = mode; }
+Fp32WideScope::~Fp32WideScope() { t_fp32_wide = prev_; }
+static int fp32_planes_process() {
+  int v = g_fp32_planes.load(std::memory_order_relaxed);
   if (v < 0) {
-    v = env_int("SX_FP32_EXACT", 0) ? 0 : 1;
-    g_fp32_split.store(v, std::memory_order_relaxed);
+    v = env_int("SX_FP32_EXACT", 0) ? 0 : (env_int("SX_FP32_PLANES", 2) == 3 ? 3 : 2);
+    g_fp32_planes.store(v, std::memory_order_relaxed);
   }
   return v;
 }
+int fp32_split_process() { return fp32_planes_process() != 0; }
+int fp32_planes() {
+  const int v = fp32_planes_process();
+  if (v == 0 || t_fp32_wide == 1) return 0;
+  return (v == 3 || t_fp32_wide == 3) ? 3 : 2;
+}
+int fp32_split() { return fp32_planes() != 0; }
 }  // namespace sx
 
+extern "C" int sx_set_fp32_planes(int planes) {
+  const int was = sx::fp32_planes_process();
+  if (planes == 0 || planes == 2 || planes == 3) sx::g_fp32_planes.store(planes, std::memory_order_relaxed);      // anything else: query only
+  return was;
+}
 extern "C" int sx_set_fp32_exact(int on) {
-  const int was = sx::fp32_split() ? 0 : 1;
-  if (on >= 0) sx::g_fp32_split.store(on ? 0 : 1, std::memory_order_relaxed);      // on < 0: query only
+  const int was = sx::fp32_planes_process() == 0 ? 1 : 0;
+  if (on >= 0) sx::g_fp32_planes.store(on ? 0 : 2, std::memory_order_relaxed);      // on < 0: query only
   return was;
 }
 extern "C" int sx_version(void) { return SX_VERSION; }

@@ -15,11 +15,11 @@ __host__ __device__ inline int64_t wpack_off_bf16(int ntaps, int kchunks, int ta
   return ((((int64_t)(row >> 4) * kchunks + (k >> 5)) * ntaps + tap) << 9) + (((((k & 31) >> 3) << 4) + (row & 15)) << 3) + (k & 7);
 }
 
-// fp32 tier in split form (conv_x3.hip): per (tap, row, 32-k chunk) 32 bf16 hi values followed by the 32 lo values
-// (hi = bf16(w), lo = bf16(w - hi)); same bytes as the plain fp32 pack [tap][row][k].  Index of the hi value in bf16
-// elements, the lo value sits 32 elements further.
-__host__ __device__ inline int64_t wpack_off_x3(int RTot, int kchunks, int tap, int row, int k) {
-  return ((((int64_t)tap * RTot + row) * kchunks + (k >> 5)) << 6) + (k & 31);
+// fp32 tier in split form (conv_x3.hip): per (tap, row, 32-k chunk) `planes` runs of 32 bf16 values -- hi = bf16(w),
+// mid = bf16(w - hi) [, lo = bf16(w - hi - mid)] -- 128 bytes (= the plain fp32 pack [tap][row][k]) with two planes, 192 with
+// three.  Index of the hi value in bf16 elements; plane q sits 32 * q elements further.
+__host__ __device__ inline int64_t wpack_off_x3(int RTot, int kchunks, int tap, int row, int k, int planes = 2) {
+  return (((int64_t)tap * RTot + row) * kchunks + (k >> 5)) * (32 * planes) + (k & 31);
 }
 
 struct ConvArgs {

@@ -267,11 +267,14 @@ __global__ void pack_weight_kernel(PackArgs A) {
       if (row < Cin && k < Cout) v = w[((int64_t)row * Cout + k) * 4 + tap];
     }
     if constexpr (sizeof(T) == 2) out[wpack_off_bf16((int)(D.total / ((int64_t)RTot * KPad)), KPad >> 5, tap, row, k)] = from_f32<T>(v);
-    else if (A.split) {
-      bf16* o2 = reinterpret_cast<bf16*>(D.out) + wpack_off_x3(RTot, KPad >> 5, tap, row, k);
-      const bf16 h = (bf16)v;
-      o2[0] = h;
-      o2[32] = (bf16)(v - (float)h);
+    else if (A.split) {          // A.split = number of bf16 planes (2 or 3)
+      bf16* o2 = reinterpret_cast<bf16*>(D.out) + wpack_off_x3(RTot, KPad >> 5, tap, row, k, A.split);
+      float r = v;
+      for (int q = 0; q < A.split; ++q) {
+        const bf16 h = (bf16)r;
+        o2[32 * q] = h;
+        r -= (float)h;
+      }
     } else out[idx] = from_f32<T>(v);
   }
 }
@@ -289,17 +292,19 @@ struct PackPair {
 static constexpr int PAIR_MAX = 32;
 struct PackPairArgs { PackPair d[PAIR_MAX]; int n; int split; };
 
-// 8 consecutive k of one row as 8 hi + 8 lo bf16 (wpack_off_x3)
-__device__ __forceinline__ void store8_split(bf16* p, const f32x8& r) {
-  bf16x8 h, l;
+// 8 consecutive k of one row as `planes` runs of 8 bf16 (wpack_off_x3)
+__device__ __forceinline__ void store8_split(bf16* p, const f32x8& r, int planes) {
+  f32x8 rest = r;
+  for (int q = 0; q < planes; ++q) {
+    bf16x8 h;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { h[i] = (bf16)r.v[i]; l[i] = (bf16)(r.v[i] - (float)h[i]); }
-  *reinterpret_cast<bf16x8*>(p) = h;
-  *reinterpret_cast<bf16x8*>(p + 32) = l;
+    for (int i = 0; i < 8; ++i) { h[i] = (bf16)rest.v[i]; rest.v[i] -= (float)h[i]; }
+    *reinterpret_cast<bf16x8*>(p + 32 * q) = h;
+  }
 }
 
 template <typename T, int NT>
-__device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int ci0, float (*tile)[32 * 9 + 1], bool split) {
+__device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int ci0, float (*tile)[32 * 9 + 1], int split) {
   constexpr int RUN = 32 * NT, TOTAL = 32 * RUN, U = 4;
   // U independent loads in flight per thread (a block is 36 trips of one load otherwise, on ~1 block per CU)
   for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * U) {
@@ -330,7 +335,7 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[hi][(lo8 + i) * NT + tap];
         if constexpr (sizeof(T) == 2) store8(of + wpack_off_bf16(NT, D.KPad_f >> 5, tap, co, ci), v);
-        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_f) + wpack_off_x3(D.RTot_f, D.KPad_f >> 5, tap, co, ci), v);
+        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_f) + wpack_off_x3(D.RTot_f, D.KPad_f >> 5, tap, co, ci, split), v, split);
         else store8(of + ((int64_t)tap * D.RTot_f + co) * D.KPad_f + ci, v);
       }
     }
@@ -340,7 +345,7 @@ __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int c
 #pragma unroll
         for (int i = 0; i < 8; ++i) v.v[i] = tile[lo8 + i][hi * NT + tap];
         if constexpr (sizeof(T) == 2) store8(ot + wpack_off_bf16(NT, D.KPad_t >> 5, NT - 1 - tap, ci, co), v);
-        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_t) + wpack_off_x3(D.RTot_t, D.KPad_t >> 5, NT - 1 - tap, ci, co), v);
+        else if (split) store8_split(reinterpret_cast<bf16*>(D.out_t) + wpack_off_x3(D.RTot_t, D.KPad_t >> 5, NT - 1 - tap, ci, co, split), v, split);
         else store8(ot + ((int64_t)(NT - 1 - tap) * D.RTot_t + ci) * D.KPad_t + co, v);
       }
     }
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairArgs A) {
   const PackPair& D = A.d[di];
   const int tb = (int)blockIdx.x - D.blk0;
   const int co0 = (tb / D.tiles_ci) * 32, ci0 = (tb % D.tiles_ci) * 32;
-  if (D.nt == 9) pack_pair_tile<T, 9>(D, co0, ci0, tile, A.split != 0);
-  else pack_pair_tile<T, 1>(D, co0, ci0, tile, A.split != 0);
+  if (D.nt == 9) pack_pair_tile<T, 9>(D, co0, ci0, tile, A.split);
+  else pack_pair_tile<T, 1>(D, co0, ci0, tile, A.split);
 }
 
 struct PackGeom { int ntaps, R, K, RPad, RTot, KPad; };
@@ -387,7 +392,9 @@ extern "C" int64_t sx_packed_weight_elems(int mode, int dtype, int c_rows, int c
   const int CK = 32;
   const int ntaps = mode == SX_CONV3 ? 9 : (mode == SX_CONVT_BWD ? 4 : 1);
   const int rtot = round_up(c_rows, 16) * (mode == SX_CONVT_FWD ? 4 : 1);
-  return (int64_t)ntaps * rtot * round_up(c_k, CK);
+  // fp32: room for the three-plane split form (192 bytes per 32 k, conv_x3.hip), whatever arithmetic mode is in force
+  const int64_t n = (int64_t)ntaps * rtot * round_up(c_k, CK);
+  return dtype == SX_F32 ? n + n / 2 : n;
 }
 
 namespace sx {
@@ -424,7 +431,7 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, 
   }
   for (size_t i0 = 0; i0 < pairs.size(); i0 += PAIR_MAX) {
     PackPairArgs A;
-    A.split = dtype == SX_F32 && fp32_split();
+    A.split = dtype == SX_F32 ? fp32_planes() : 0;
     A.n = (int)std::min<size_t>(PAIR_MAX, pairs.size() - i0);
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
@@ -446,7 +453,7 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, 
   for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
     PackArgs A;
     memset(&A.pad, 0, sizeof(A.pad));
-    A.split = dtype == SX_F32 && fp32_split();
+    A.split = dtype == SX_F32 ? fp32_planes() : 0;
     if (pad && i0 == 0) A.pad = *pad;
     A.n = std::min(PACK_MAX, n - i0);
     int blk = 0;

@@ -15,17 +15,45 @@
 
 namespace sx {
 
-static constexpr int ROW3 = 160;     // LDS bytes per staged row: 32 bf16 hi, 32 bf16 lo, 32 bytes of padding
-static constexpr int LOFF = 64;      // the lo plane inside a row
+// LDS bytes per staged row: PL planes of 32 bf16 (64 bytes each) + 32 bytes of padding.  160 (two planes) and 224 (three):
+// stride / 16 = 2 * odd, conflict-free under ds_read_b128's lane grouping (208 and 192 take 8 LDS cycles per read, not 4).
+// The WEIGHT image of the three-plane form is stored unpadded (192 bytes per row, 8 cycles per fragment read): nine taps x
+// 64 rows at 224 bytes do not fit beside the pixel image (169 KB), and a 32-channel tile stages every pixel twice as often
+// (measured: cfg 5 fp32 step 31.1 ms with 32-channel tiles).
+template <int PL> struct X3Row { static constexpr int BYTES = PL * 64 + 32; static constexpr int WBYTES = PL == 3 ? 192 : BYTES; };
 
-// 4 floats -> 4 bf16 hi + 4 bf16 lo (round to nearest even; the difference v - hi is exact in fp32)
-__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+// THREE planes ("x6", round 3): v = hi + mid + lo + r, |r| <= 2^-27 |v|, and a product keeps the six terms down to 2^-18
+// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped mid*lo, lo*mid, lo*lo are <= 2^-27): fp32-grade products at six
+// bf16 MFMAs per block (96 matrix-core cycles against 256 of the exact kernels).  Used where two planes were measured outside
+// the 1e-4 contract: networks whose widest layer reaches 512 channels (unet_plan.hip).
+
+// 4 floats -> PL bf16 planes (round to nearest even; every difference is exact in fp32)
+template <int PL>
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4 (&pl)[PL]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bf16 h = (bf16)v[e];
-    hi[e] = h;
-    lo[e] = (bf16)(v[e] - (float)h);
+    float r = v[e];
+#pragma unroll
+    for (int q = 0; q < PL; ++q) {
+      const bf16 h = (bf16)r;
+      pl[q][e] = h;
+      r -= (float)h;
+    }
   }
+}
+
+// acc += A * B over the kept cross terms, small terms first; A / B indexed [plane]
+template <int PL>
+__device__ __forceinline__ f32x4 x3_mma(const bf16x8 (&A)[PL], const bf16x8 (&B)[PL], f32x4 acc) {
+  if constexpr (PL == 3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[1], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[0], acc, 0, 0, 0);
+  return acc;
 }
 
 // One block = WM x WN waves, a tile of WM*MI*16 output channels x WN*NI*16 pixels.  Blocks are persistent: a block walks
@@ -33,12 +61,14 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 // prefetch of the next stage also runs across tile boundaries and under the epilogue; with a single K chunk the weight
 // image stays in LDS for every tile of the block.  Fragments of tap t+1 are read while the MFMAs of tap t run.
 // NPX: pixel pieces (16 bytes = 4 fp32 channels) a thread stages per chunk.
-template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS != 4) ? 2 : 1) void conv_x3_kernel(ConvArgs a) {     // <= 32-channel tiles: two blocks per CU
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false, int PL = 2>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS != 4 && PL == 2) ? 2 : 1) void conv_x3_kernel(ConvArgs a) {     // <= 32-channel tiles: two blocks per CU
   constexpr int NT = WM * WN * 64;
   constexpr int BMC = WM * MI * 16;
   constexpr int TAPW = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
-  constexpr int NPW = (TAPS * BMC * 8 + NT - 1) / NT;       // weight pieces per thread
+  constexpr int ROW3 = X3Row<PL>::BYTES, WROW = X3Row<PL>::WBYTES;
+  constexpr int WPR = 4 * PL;                                // 16-byte pieces of one packed (row, chunk): PL planes of 64 bytes
+  constexpr int NPW = (TAPS * BMC * WPR + NT - 1) / NT;      // weight pieces per thread
   extern __shared__ __align__(16) char smem[];
   char* sm_pix = smem;
   char* sm_w = smem + a.LH * a.LW * ROW3;
@@ -58,13 +88,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
   }
   int w_off[MI];
 #pragma unroll
-  for (int j = 0; j < MI; ++j) w_off[j] = ((wm * MI + j) * 16 + n) * ROW3 + g * 16;
+  for (int j = 0; j < MI; ++j) w_off[j] = ((wm * MI + j) * 16 + n) * WROW + g * 16;
 
   const float* __restrict__ xg = reinterpret_cast<const float*>(a.x);
   const char* __restrict__ wg = reinterpret_cast<const char*>(a.w);
   float* __restrict__ yg = reinterpret_cast<float*>(a.y);
   const int npix_pieces = a.LH * a.LW * 8;
-  constexpr int nw_pieces = TAPS * BMC * 8;
+  constexpr int nw_pieces = TAPS * BMC * WPR;
   const int kch = a.KPad >> 5;
   // CENTER (the joint data gradient of conv1 + 1x1 shortcut, sx_conv3_shortcut_dgrad): the input holds 2K channels
   // [dY1 | dR]; chunks of the second half only feed the centre tap, with the 1x1 weights w2 staged in the image of tap 0
@@ -87,10 +117,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
   }
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int p = tid + i * NT, r = p >> 3, q = p & 7;
+    const int p = tid + i * NT, r = p / WPR, q = p - r * WPR;
     const int tap = r / BMC, row = r - tap * BMC;
     const bool ok = p < nw_pieces && cb + row < a.RTot;
-    pw_off[i] = ok ? (((tap * a.RTot + cb + row) * kch) << 7) + q * 16 : -1;
+    pw_off[i] = ok ? ((tap * a.RTot + cb + row) * kch) * (64 * PL) + q * 16 : -1;
   }
   struct Tile { int b, ty0, tx0; };
   auto tile_at = [&](int t) {
@@ -117,14 +147,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
         for (int i = 0; i < NPW; ++i) {
           const int p = tid + i * NT;
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (p < BMC * 8 && pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg2 + (pw_off[i] + (((kc - a.KPad) >> 5) << 7)));
+          if (p < BMC * WPR && pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg2 + (pw_off[i] + ((kc - a.KPad) >> 5) * (64 * PL)));
           pre_w[i] = v;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + (pw_off[i] + ((kc >> 5) << 7)));
+          if (pw_off[i] >= 0) v = *reinterpret_cast<const u32x4*>(wg + (pw_off[i] + (kc >> 5) * (64 * PL)));
           pre_w[i] = v;
         }
       }
@@ -151,11 +181,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
       for (int i = 0; i < NPX; ++i) {
         const int p = tid + i * NT;
         if (p < npix_pieces) {
-          bf16x4 hi, lo;
-          split4(pre_x[i], hi, lo);
+          bf16x4 pl[PL];
+          split4<PL>(pre_x[i], pl);
           char* dst = sm_pix + (p >> 3) * ROW3 + (p & 7) * 8;
-          *reinterpret_cast<bf16x4*>(dst) = hi;
-          *reinterpret_cast<bf16x4*>(dst + LOFF) = lo;
+#pragma unroll
+          for (int q = 0; q < PL; ++q) *reinterpret_cast<bf16x4*>(dst + 64 * q) = pl[q];
         }
       }
       const bool second = CENTER && kc >= a.KPad;
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
           const int p = tid + i * NT;
-          if (p < (second ? BMC * 8 : nw_pieces)) *reinterpret_cast<u32x4*>(sm_w + (p >> 3) * ROW3 + (p & 7) * 16) = pre_w[i];
+          if (p < (second ? BMC * WPR : nw_pieces)) *reinterpret_cast<u32x4*>(sm_w + (p / WPR) * WROW + (p % WPR) * 16) = pre_w[i];
         }
       }
       __syncthreads();
@@ -174,22 +204,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
       if constexpr (CENTER) {
         if (second) {            // centre tap only: pixel (py + 1, px + 1) of the halo image, weights in the image of tap 0
           const int toff = (a.LW + 1) * ROW3;
-          bf16x8 Ah[MI], Al[MI];
+          bf16x8 Ac[MI][PL];
 #pragma unroll
-          for (int j = 0; j < MI; ++j) {
-            Ah[j] = *reinterpret_cast<const bf16x8*>(sm_w + w_off[j]);
-            Al[j] = *reinterpret_cast<const bf16x8*>(sm_w + w_off[j] + LOFF);
-          }
+          for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int q = 0; q < PL; ++q) Ac[j][q] = *reinterpret_cast<const bf16x8*>(sm_w + w_off[j] + 64 * q);
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff);
-            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + LOFF);
+            bf16x8 Bc[PL];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[j], Bh, acc[j][i], 0, 0, 0);
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bl, acc[j][i], 0, 0, 0);
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[j], Bh, acc[j][i], 0, 0, 0);
-            }
+            for (int q = 0; q < PL; ++q) Bc[q] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + 64 * q);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[j][i] = x3_mma<PL>(Ac[j], Bc, acc[j][i]);
           }
           continue;
         }
@@ -197,22 +223,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
 
       // one wave per SIMD: the fragments of tap t+1 are read while the MFMAs of tap t run (two register sets); with two
       // waves per SIMD the other wave covers the LDS latency and one set keeps the kernel inside 256 VGPRs
-      constexpr int NS = NT == 256 ? 2 : 1;
-      bf16x8 Ah[NS][MI], Al[NS][MI], Bh[NS][NI], Bl[NS][NI];
+      constexpr int NS = (NT == 256 && !(PL == 3 && CENTER && MI * NI >= 8)) ? 2 : 1;      // (that one spills 256 bytes per lane with two sets)
+      bf16x8 Af[NS][MI][PL], Bf[NS][NI][PL];
       auto read_tap = [&](int tap, int slot) {
         const int tyy = tap / TAPW, txx = tap - tyy * TAPW;
         const int toff = (tyy * a.LW + txx) * ROW3;
-        const char* wt = sm_w + tap * BMC * ROW3;
+        const char* wt = sm_w + tap * BMC * WROW;
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
-          Ah[slot][j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j]);
-          Al[slot][j] = *reinterpret_cast<const bf16x8*>(wt + w_off[j] + LOFF);
-        }
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          Bh[slot][i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff);
-          Bl[slot][i] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + LOFF);
-        }
+          for (int q = 0; q < PL; ++q) Af[slot][j][q] = *reinterpret_cast<const bf16x8*>(wt + w_off[j] + 64 * q);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int q = 0; q < PL; ++q) Bf[slot][i][q] = *reinterpret_cast<const bf16x8*>(sm_pix + pix_off[i] + toff + 64 * q);
       };
       if constexpr (NS == 2) read_tap(0, 0);
 #pragma unroll
@@ -224,19 +248,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
         } else {
           read_tap(tap, 0);
         }
-        // the two small terms first, the leading term last
+        // the small terms first, the leading term last; term by term over the tile so that consecutive MFMAs hit different accumulators
+        if constexpr (PL == 3) {
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][2], Bf[sl][i][0], acc[j][i], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][0], Bf[sl][i][2], acc[j][i], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][1], Bf[sl][i][1], acc[j][i], 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[sl][j], Bh[sl][i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][1], Bf[sl][i][0], acc[j][i], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[sl][j], Bl[sl][i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][0], Bf[sl][i][1], acc[j][i], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < MI; ++j)
 #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[sl][j], Bh[sl][i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < NI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[sl][j][0], Bf[sl][i][0], acc[j][i], 0, 0, 0);
         if constexpr (NS == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -289,15 +327,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && WM * MI <= 2 && TAPS
   }
 }
 
-template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false>
+template <int TAPS, int MI, int NI, int WM, int WN, int NPX, bool CENTER = false, int PL = 2>
 static int launch_x3(ConvArgs a, hipStream_t st) {
+  constexpr int ROW3 = X3Row<PL>::BYTES;
   constexpr int NT = WM * WN * 64;
   constexpr int BMC = WM * MI * 16, TP = WN * NI * 16;
   const int taph = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
   a.TH = TP / a.TW;
   a.LH = (a.TH - 1) * a.in_scale + taph;
   a.tiles_y = cdiv(a.H, a.TH);
-  size_t smem = (size_t)(a.LH * a.LW + TAPS * BMC) * ROW3;
+  size_t smem = (size_t)a.LH * a.LW * ROW3 + (size_t)TAPS * BMC * X3Row<PL>::WBYTES;
   const size_t stat_bytes = (size_t)WN * BMC * 2 * sizeof(float);
   if (smem < stat_bytes) smem = stat_bytes;
   if (smem > 160 * 1024) { set_error("conv tile needs %zu B of LDS", smem); return SX_ERR_UNSUPPORTED; }
@@ -306,14 +345,14 @@ static int launch_x3(ConvArgs a, hipStream_t st) {
     return SX_ERR_UNSUPPORTED;
   }
   if ((int64_t)a.Hx * a.Wx * a.x_ld >= ((int64_t)1 << 31)) { set_error("conv: one sample exceeds 2^31 elements"); return SX_ERR_UNSUPPORTED; }
-  auto kern = conv_x3_kernel<TAPS, MI, NI, WM, WN, NPX, CENTER>;
+  auto kern = conv_x3_kernel<TAPS, MI, NI, WM, WN, NPX, CENTER, PL>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_x3)"));
   // persistent grid: as many blocks as the LDS images allow on 256 CUs (2 in flight per CU at least when they are small)
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const int gy = cdiv(a.RTot, BMC);
   // resident blocks per CU as the runtime computes it from registers and LDS (cached per 4 KB bucket of LDS: the query is a host call)
-  static std::atomic<int> occ[41];
+  static std::atomic<int> occ[41];      // (per instantiation)
   int per_cu = occ[smem >> 12].load(std::memory_order_relaxed);
   if (per_cu == 0) {
     int nb = 0;
@@ -331,6 +370,12 @@ static int launch_x3(ConvArgs a, hipStream_t st) {
 
 template <int TAPS, int NPX, bool CENTER = false>
 static int x3_tiles(const ConvArgs& a, hipStream_t st) {
+  if (fp32_planes() == 3) {
+    // three planes: 64 channels x 128 pixels on four waves (the 256-pixel form's images exceed the LDS)
+    if (a.RTot <= 16) return launch_x3<TAPS, 1, 2, 1, 4, NPX, CENTER, 3>(a, st);
+    if (a.RTot <= 32 || TAPS == 4) return launch_x3<TAPS, 2, 2, 1, 4, NPX, CENTER, 3>(a, st);     // (transposed data gradient: a 16 x 32 pixel image)
+    return launch_x3<TAPS, 2, 4, 2, 2, NPX, CENTER, 3>(a, st);
+  }
   if (a.RTot <= 16) return launch_x3<TAPS, 1, 2, 1, 4, NPX, CENTER>(a, st);
   if (a.RTot <= 32) return launch_x3<TAPS, 2, 2, 1, 4, NPX, CENTER>(a, st);
   // 64 channels x 256 pixels on 8 waves where a sample has that many pixels in tiles of this width (half the weight

@@ -162,15 +162,19 @@ int fp32_split();
 // grid, tools/fp32_mix.py: the split arithmetic's error comes from the forward / data-gradient convolutions alone --
 // convolutions split 3.95e-4 with exact or split weight gradients, convolutions exact 3.31e-5 with either)
 int fp32_split_process();
-// While alive on this thread, fp32_split() answers "exact" whatever the process-wide mode is: the whole-network entry points
-// (unet_plan.hip) use it for architectures where split arithmetic was measured outside the 1e-4 contract.
-struct Fp32ExactScope {
-  explicit Fp32ExactScope(bool on);
-  ~Fp32ExactScope();
-  Fp32ExactScope(const Fp32ExactScope&) = delete;
-  Fp32ExactScope& operator=(const Fp32ExactScope&) = delete;
+// bf16 planes of the split arithmetic in force: 0 = exact fp32 MFMA, 2 = hi + lo (three MFMAs per block), 3 = hi + mid + lo
+// (six MFMAs, fp32-grade products).  fp32_split() == (fp32_planes() != 0).
+int fp32_planes();
+// While alive on this thread the convolutions of wide networks leave the two-plane kernels: mode 3 = three planes, 1 = exact,
+// 0 = no change.  The whole-network entry points (unet_plan.hip) use it for architectures where two planes were measured
+// outside the 1e-4 contract.
+struct Fp32WideScope {
+  explicit Fp32WideScope(int mode);
+  ~Fp32WideScope();
+  Fp32WideScope(const Fp32WideScope&) = delete;
+  Fp32WideScope& operator=(const Fp32WideScope&) = delete;
  private:
-  bool on_;
+  int prev_;
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

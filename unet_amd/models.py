@@ -282,7 +282,7 @@ class UNet(nn.Module):
         # storage or version counter changed; in training mode they are rebuilt every forward.
         # `_wgen` counts updates made through raw pointers (TrainEngine's AdamW kernel), which bump no version counter.
         # fp32 packs also depend on the arithmetic mode they were made in (split-bf16 / exact, sx_set_fp32_exact).
-        key = (self._wgen, L.lib().sx_set_fp32_exact(-1)) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (self._wgen, L.lib().sx_set_fp32_planes(-1)) + tuple((p.data_ptr(), p._version) for p in params)
         ckey = (dtype, str(device))
         ent = self._wcache.get(ckey)
         sess = UNetSession(self._cfg, B, H, W, dtype, use_film, device, wpack=None if ent is None else ent[1])
