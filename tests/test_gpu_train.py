@@ -159,18 +159,26 @@ def test_engine_step_equals_autograd_path_and_oracle_adamw(fp32_mode):
     ga = {k: p.grad.clone() for k, p in a.named_parameters()}
     for k, p in b.named_parameters():
         assert rel_err(p.grad.cpu(), ga[k].cpu()) < 1e-4, k
+    # The optimizer kernel against the oracle's clip + AdamW ON THE GRADIENT THE ENGINE HOLDS (equal to the autograd path's to
+    # 1e-4, just checked).  Feeding the oracle the OTHER path's gradient made this a test of sign flips: step-1 Adam moves every
+    # weight by ~lr * sign(g), so elements within the atomic-order noise of zero flip between two runs (one run in ~10 landed at
+    # 5e-4 against a 3e-4 bound); with the same gradient on both sides the bound is fp32 rounding.
     names = list(ga)
-    clipped, total = optim_ref.clip_grad_norm([ga[k].cpu() for k in names], 0.5)
+    gb = {k: p.grad.detach().cpu().clone() for k, p in b.named_parameters()}
+    clipped, total = optim_ref.clip_grad_norm([gb[k] for k in names], 0.5)
     eng.optimizer_step(1e-2)
     torch.cuda.synchronize()
-    assert abs(float(eng.gnorm) - float(total)) < 1e-4 * float(total)
+    assert abs(float(eng.gnorm) - float(total)) < 1e-5 * float(total)
     pb = dict(b.named_parameters())
     for k, g in zip(names, clipped):
         pn, _, _ = optim_ref.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-2, weight_decay=1e-4)
-        # step-1 Adam moves every weight by ~lr*sign(g): a gradient element within the run-to-run atomic-order noise
-        # of zero may flip, which costs ~1e-5 of the tensor norm per flipped element.  The split-bf16 arithmetic carries
-        # ~4e-6 per convolution instead of ~2e-7, so more of the near-zero elements flip there: 3e-4 (measured 1.1e-4)
-        assert rel_err(pb[k].detach().cpu(), pn) < (1e-4 if fp32_mode == "exact" else 3e-4), k
+        assert rel_err(pb[k].detach().cpu(), pn) < 1e-5, k
+    # ... and elements that cannot flip (|g| well above the noise) agree with the autograd path's update too
+    for k in names:
+        big = ga[k].cpu().abs() > 1e-2 * ga[k].cpu().abs().max()
+        ua = -1e-2 * torch.sign(ga[k].cpu())[big]
+        ub = (pb[k].detach().cpu() - sd[k] * (1 - 1e-2 * 1e-4))[big]
+        assert float((ua - ub).abs().max()) < 2e-2 * 1e-2, k
 
 
 def test_load_checkpoint_depth3_round_trip(tmp_path):

@@ -406,14 +406,16 @@ static int wg_min_tiles(bool ct) { static const int v = env_int("SX_WG_MIN_TILES
 // at 64 blocks each the 13 problems of a half left the chip to a few 0.5 ms blocks (decoder half 1.45 ms at 22 % of the
 // MFMA peak; cfg 5 step 7.28 -> 6.70 ms with 100 MFLOP per block, 6.89 with 200, 6.95 with 400).  cfg A wants the opposite
 // (a block's fixed cost of ~8 us against 10-20 GFLOP problems: 1.68 ms per step at 400 MFLOP per block = 64 blocks each,
-// 1.69 at 200, 1.72 at 100), so the finer split starts at 30 GFLOP.  SX_WG_BLOCK_MFLOP overrides both; <= 512 blocks per
+// 1.69 at 200, 1.72 at 100), so the finer split starts at 45 GFLOP (cfg A's largest problem, the fused conv1 + shortcut of
+// the last decoder, counts 38.6 with its centre-tap-only rows).  SX_WG_BLOCK_MFLOP overrides both; <= 512 blocks per
 // problem (the slab reservation, wgrad_ws_slab_bytes, covers whichever plan is larger).
 static constexpr int WG_MAX_BLOCKS = 512;
 static int wg_target_blocks(bool batched, double mflop) {
   static const int v = std::min(std::max(env_int("SX_WG_TARGET", 0), 0), 256);
   static const int per_block_env = env_int("SX_WG_BLOCK_MFLOP", 0);
   if (!batched) return 256;
-  const int per_block = per_block_env > 0 ? per_block_env : (mflop > 30000.0 ? 100 : 400);
+  static const int fine_gf = env_int("SX_WG_FINE_GF", 45);
+  const int per_block = per_block_env > 0 ? per_block_env : (mflop > 1e3 * fine_gf ? 100 : 400);
   const int by_cost = (int)std::min<double>(WG_MAX_BLOCKS, mflop / per_block + 1.0);
   return std::max(v > 0 ? v : 64, by_cost);
 }
