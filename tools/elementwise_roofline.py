@@ -26,7 +26,8 @@ def kname(n):
 
 step = [(pos, rows[idx[-2] + 1 + pos][0]) for pos in range(per)]
 out = []
-fi = bi = 0          # forward block counter (two launches per block), backward launch counter (four per block)
+fi = 0               # forward block counter (two launches per block)
+bblk = bstate = 0    # backward block counter and position inside the block
 fwd_in_block = 0
 pool_f = pool_b = 0
 for pos, name in step:
@@ -40,22 +41,26 @@ for pos, name in step:
             fwd_in_block = 1
         else:
             if k == "act_fwd_pool":
-                byt, what = 3.25 * T[lvl], f"block out + max-pool   L{lvl}: read Y,S, write O,O/4"
+                byt, what = 3.375 * T[lvl], f"block out + max-pool   L{lvl}: read Y,S, write O,O/4,positions"
             else:
                 byt, what = 3 * T[lvl], f"block out fwd          L{lvl}: read Y,S, write O"
             fwd_in_block = 0
             fi += 1
     elif k in ("act_bwd_reduce", "act_bwd_apply"):
-        lvl = LEVELS[bi // 4]
-        j = bi % 4
-        if j == 0: byt, what = 3 * T[lvl], f"block out bwd, sums    L{lvl}: read Y,dO,S"
-        if j == 1: byt, what = 4 * T[lvl], f"block out bwd, apply   L{lvl}: read Y,dO, write dY,dR"
-        if j == 2: byt, what = 2 * T[lvl], f"GN+SiLU bwd, sums      L{lvl}: read Y,dO"
-        if j == 3: byt, what = 3 * T[lvl], f"GN+SiLU bwd, apply     L{lvl}: read Y,dO, write dY"
-        bi += 1
-    elif k == "maxpool_bwd_add":
+        # per DoubleConv block, backward: block-output sums, block-output apply, [GroupNorm-1 sums unless conv2's data gradient
+        # took them in its epilogue], GroupNorm-1 apply
+        lvl = LEVELS[bblk]
+        if bstate == 0: byt, what, bstate = 3 * T[lvl], f"block out bwd, sums    L{lvl}: read Y,dO,S", 1
+        elif bstate == 1: byt, what, bstate = 4 * T[lvl], f"block out bwd, apply   L{lvl}: read Y,dO, write dY,dR", 2
+        elif bstate == 2 and k == "act_bwd_reduce": byt, what, bstate = 2 * T[lvl], f"GN+SiLU bwd, sums      L{lvl}: read Y,dO", 3
+        else:
+            byt, what = 3 * T[lvl], f"GN+SiLU bwd, apply     L{lvl}: read Y,dO, write dY"
+            bstate = 0
+            bblk += 1
+    elif k in ("maxpool_bwd_add", "maxpool_bwd_add_idx"):
         lvl = [2, 1, 0][pool_b]; pool_b += 1
-        byt, what = 3.25 * T[lvl], f"max-pool bwd + skip    L{lvl}: read O,dskip,dP, write dO"
+        if k.endswith("idx"): byt, what = 2.375 * T[lvl], f"max-pool bwd + skip    L{lvl}: read positions,dskip,dP, write dO"
+        else: byt, what = 3.25 * T[lvl], f"max-pool bwd + skip    L{lvl}: read O,dskip,dP, write dO"
     elif k == "maxpool_fwd":
         lvl = [0, 1, 2][pool_f]; pool_f += 1
         byt, what = 1.25 * T[lvl], f"max-pool fwd           L{lvl}"

@@ -12,4 +12,5 @@ python3 $root/tools/prof_cats.py $db 25 > $root/gpurun_out/${tag}_families.txt
 n=$(python3 -c "import sqlite3,sys; print(sqlite3.connect(sys.argv[1]).execute('select count(*) from kernels').fetchone()[0])" $db)
 per=$((n / 25))
 python3 $root/tools/prof_seq.py $db $((n - per - 2)) $((per + 4)) > $root/gpurun_out/${tag}_sequence.txt
+python3 $root/tools/elementwise_roofline.py $db > $root/gpurun_out/${tag}_elementwise.txt 2>&1
 rm -rf $root/gpurun_out/$tag
