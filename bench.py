@@ -212,7 +212,7 @@ def measure_infer(model, x, p, dtype, steps, warmup, world, sync, dev):
     return world * x.shape[0] * steps / dt
 
 
-TRAFFIC_FILE = "profiles/r02_conv_ws_traffic.json"
+TRAFFIC_FILE = "profiles/r03_conv_ws_traffic.json"
 
 
 def conv_traffic(a):
