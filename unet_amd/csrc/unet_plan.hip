@@ -292,10 +292,16 @@ struct WgQueue {
   }
   int flush() {
     if (!launches.empty()) {
-      // longest problems first: the short ones fill the tail (cost ~ operand bytes x taps)
+      // longest BLOCKS first (estimated block time: arithmetic at 4 TFLOP/s per CU + operand bytes at 60 GB/s per CU, over
+      // the problem's block count): the short ones fill the tail.  SX_WG_SORT_BLOCK=0: by whole-problem cost (rounds 1-2;
+      // cfg 5 6.54 -> 6.50 ms, cfg A 1.704 -> 1.698 ms, same box)
       std::stable_sort(launches.begin(), launches.end(), [](const WgWsLaunch& x, const WgWsLaunch& y) {
+        static const int per_block = env_int("SX_WG_SORT_BLOCK", 1);
         auto cost = [](const WgWsLaunch& l) {
-          return (double)l.a.B * l.a.H * l.a.W * (l.a.CaPad + l.a.CbPad) * (l.variant >> 8 & 15);
+          const double c = (double)l.a.B * l.a.H * l.a.W * (l.a.CaPad + l.a.CbPad) * (l.variant >> 8 & 15);
+          if (!per_block) return c;
+          const double px = (double)l.a.B * l.a.H * l.a.W, taps = l.variant >> 8 & 15;
+          return (2.0 * px * taps * l.a.CaPad * l.a.CbPad / 4e12 + 2.0 * px * (l.a.CaPad + l.a.CbPad) / 6e10) / std::max(1, l.blocks);
         };
         return cost(x) > cost(y);
       });
