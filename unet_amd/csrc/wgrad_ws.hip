@@ -453,7 +453,7 @@ static WgWsPlan wgws_plan(int mode, int B, int H, int W, int Ca, int Cb, bool ba
   // queues its R partners on the few that have one (cfg 5, transposed conv 512 -> 256: R = 64, S = 1: 377 us on one XCD;
   // with >= 8 splits cfg 5's decoder half 1263 -> 810 us, step 7.00 -> 6.54 ms; cfg A 1.715 -> 1.704 ms, same box)
   static const int min_splits = env_int("SX_WG_MIN_SPLITS", 8);
-  if (batched && S < min_splits) S = std::max(S, std::min(min_splits, std::max(1, p.ntiles / wg_min_tiles(ct))));
+  if (S < min_splits) S = std::max(S, std::min(min_splits, std::max(1, p.ntiles / wg_min_tiles(ct))));
   p.tiles_per_split = cdiv(p.ntiles, S);
   p.S = cdiv(p.ntiles, p.tiles_per_split);
   p.slab_bytes = (int64_t)p.S * p.taps * p.CaPad * p.CbPad * 4;
