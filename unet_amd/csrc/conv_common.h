@@ -33,6 +33,7 @@ struct ConvArgs {
   int ntaps, tapw;
   int in_scale, pad;
   int shuffle, accumulate;
+  int epi_counted;    // conv_ws: full tiles store through counted instructions (set by the launcher; SX_WS_EPI_COUNTED=0: A/B knob)
   int tw_log2, TW, TH, LW, LH;
   int tiles_x, tiles_y;
   int cpg;

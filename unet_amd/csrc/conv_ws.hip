@@ -28,8 +28,27 @@
 namespace sx {
 
 static constexpr bool WS_DBG = SX_WS_DBG != 0;
+#ifndef SX_WS_ABL
+#define SX_WS_ABL 0        // diagnostic builds only (wrong results): bit 0 no epilogue stores, bit 1 no statistics arithmetic
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// four bf16 outputs as exactly ONE vector-memory instruction (the stage waits below count the stores of full tiles)
+__device__ __forceinline__ void store4_counted(bf16* p, f32x4 v) {
+  const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  union { bf16x4 b; u32x2 u; } c;
+  c.b = o;
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(c.u) : "memory");
+}
+// s_waitcnt vmcnt(BASE + c * STEP), c in 0..3 (wave-uniform)
+template <int BASE, int STEP> __device__ __forceinline__ void wait_vmcnt_plus(int c) {
+  static_assert(BASE + 3 * STEP <= 63, "vmcnt field");
+  if (c == 0) wait_vmcnt<BASE>();
+  else if (c == 1) wait_vmcnt<BASE + STEP>();
+  else if (c == 2) wait_vmcnt<BASE + 2 * STEP>();
+  else wait_vmcnt<BASE + 3 * STEP>();
+}
 
 // sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane ends with the total
 __device__ __forceinline__ float row_sum16(float v) {
@@ -314,6 +333,9 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
   };
 
   unsigned long long dbg_wait = 0, dbg_issue = 0, dbg_epi = 0, dbg_last = 0;
+  constexpr int NST = MI * NI * (VAR == WS_DUAL ? 2 : 1);                    // stores of one full-tile epilogue
+  constexpr bool FASTEPI = !BS && (DIST - 1) * NP + 3 * NST <= 63 && DIST <= 3;
+  int epf0 = 0, epf1 = 0, epf2 = 0;                // 1: the epilogue 0 / 1 / 2 tiles back issued exactly NST stores (wave-uniform)
   for (int t = t_begin; t < t_end; ++t) {
     f32x4 acc[MI][NI], acc2[VAR == WS_DUAL ? MI : 1][VAR == WS_DUAL ? NI : 1];
     // register-heavy instantiations (288 weight VGPRs and two channel fragments per wave) prefetch the first fragment row
@@ -332,7 +354,21 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
 #pragma unroll
     for (int kc = 0; kc < KTOT; ++kc, ++s) {
       const unsigned long long d0 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
-      wait_vmcnt<(DIST - 1) * NP>();                 // this wave's pieces of stage s have landed
+      // this wave's pieces of stage s have landed.  vmcnt retires in issue order and counts stores too: what may still be
+      // in flight is the DIST - 1 newer stages AND the output stores of every epilogue since stage s was requested (DIST
+      // stages ago) -- without that term each tile start waited for the previous tile's write acknowledgements.  Only
+      // epilogues that issued exactly NST stores (full tiles, store4_counted) are counted; anything else counts as zero,
+      // which only waits longer.
+      if constexpr (FASTEPI) {
+        int c = 0;
+        if (kc <= DIST - 1) {
+          const int M = (DIST - 1 - kc) / KTOT;     // epilogues 0..M tiles back fall inside the window (compile-time after unrolling)
+          c = epf0 + (M >= 1 ? epf1 : 0) + (M >= 2 ? epf2 : 0);
+        }
+        wait_vmcnt_plus<(DIST - 1) * NP, NST>(c);
+      } else {
+        wait_vmcnt<(DIST - 1) * NP>();
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // and its LDS reads of stage s-1 have returned
       __builtin_amdgcn_s_barrier();                  // ... for every wave: buffer (s-1) % NBUF is free
       const unsigned long long d1 = WS_DBG ? __builtin_amdgcn_s_memtime() : 0;
@@ -419,6 +455,7 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
     bf16* y2tile = VAR == WS_DUAL ? reinterpret_cast<bf16*>(a.y2) + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.y2_ld : nullptr;
     const bool xvalid = cp.tx * TW + nc < a.W;
     const int rows_left = a.H - cp.ty * TH - wn * NI * RPF - nr;   // valid rows below this lane's first row
+    bool full_tile = false;
     if (TAPS == 1 && VAR == WS_PLAIN && a.shuffle) {
       // ConvTranspose2d(2,2) as four 1x1 GEMMs: row = tap*RPad + co, the output pixel of input pixel (y, x) under tap
       // (ty, tx) is (2y + ty, 2x + tx); bias added here (models.py:190)
@@ -438,6 +475,20 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
           }
         }
       }
+    } else if (FASTEPI && a.epi_counted && !a.accumulate && (cp.tx + 1) * TW <= a.W && (cp.ty + 1) * TH <= a.H && cb + BMC <= a.R) {
+      // full tile, every channel valid: NST unconditional stores, counted by the stage waits of the next tile(s)
+      full_tile = true;
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const f32x4 v = acc[j][i];
+          if (!(SX_WS_ABL & 1)) store4_counted(ytile + (unsigned)(lane_out + i * RPF * out_row + j * 16), v);
+          if (SX_WS_ABL & 2) { s1[j] += v; }
+          else if (do_stats) { s1[j] += v; s2[j] += v * v; }
+          else if (do_chsum) s1[j] += v;
+          if constexpr (VAR == WS_DUAL) { if (!(SX_WS_ABL & 1)) store4_counted(y2tile + (unsigned)(lane_out2 + i * RPF * out_row2 + j * 16), acc2[j][i]); else s1[j] += acc2[j][i]; }
+        }
     } else {
     if constexpr (BS_HEAVY) {
       const bf16* yt = bsY + ((int64_t)(cp.b * a.Hy + cp.ty * TH) * a.Wy + cp.tx * TW) * a.bs_y_ld;
@@ -479,15 +530,17 @@ __global__ __launch_bounds__(256, NBUF == 3 ? 2 : 1) void conv_ws_kernel(ConvArg
                 s4[j][r] += gq;
               }
             }
-          } else
+          } else if (!(SX_WS_ABL & 1))
           store4(dst, v);
-          if (do_stats) { s1[j] += v; s2[j] += v * v; }
+          if (SX_WS_ABL & 2) { s1[j] += v; }
+          else if (do_stats) { s1[j] += v; s2[j] += v * v; }
           else if (do_chsum) s1[j] += v;
-          if constexpr (VAR == WS_DUAL) store4(y2tile + (unsigned)(lane_out2 + i * RPF * out_row2 + j * 16), acc2[j][i]);
+          if constexpr (VAR == WS_DUAL) { if (!(SX_WS_ABL & 1)) store4(y2tile + (unsigned)(lane_out2 + i * RPF * out_row2 + j * 16), acc2[j][i]); else s1[j] += acc2[j][i]; }
         }
       }
     }
     }
+    epf2 = epf1; epf1 = epf0; epf0 = (full_tile && !(SX_WS_ABL & 1)) ? 1 : 0;
     if (WS_DBG) dbg_epi += __builtin_amdgcn_s_memtime() - d3;
     const int b_done = cp.b;
     cp.next(a.tiles_x, a.tiles_y);
@@ -546,13 +599,16 @@ static int launch_ws(ConvArgs a, hipStream_t st) {
   constexpr bool TWO = (TAPS == 9 && KCH == 1 && MI == 2 && NI == 4 && TWL == 4) ||
                        (VAR == WS_CENTER && KCH == 1 && MI == 2) || (TAPS == 9 && KCH == 2 && MI == 1 && NI == 8 && TWL == 4) ||
                        (TAPS == 9 && KCH == 4 && MI == 1 && NI == 8 && TWL == 4 && (VAR == WS_PLAIN || VAR == WS_CENTER)) ||
-                       (VAR == WS_PLAIN && TAPS == 1 && KCH <= 2 && TWL == 4);
+                       (VAR == WS_PLAIN && TAPS == 1 && KCH <= 2 && TWL == 4) ||
+                       (VAR == WS_DUAL && KCH == 2 && MI == 1 && NI == 4 && WM == 2 && TWL == 4);
   constexpr int NBUF = TWO ? 3 : SX_WS_NBUF;                    // NBUF - 1 stages in flight per block
   const size_t smem = (size_t)NBUF * NP * 4096 + (size_t)WN * BMC * (VAR == WS_BS ? 4 : 2) * sizeof(float);
   auto kern = conv_ws_kernel<KCH, TAPS, MI, NI, WM, WN, NBUF, TWL, VAR>;
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(kern), done, "hipFuncSetAttribute(conv_ws)"));
   a.TH = TH; a.TW = TW;
+  static const int epi_counted = env_int("SX_WS_EPI_COUNTED", 1);
+  a.epi_counted = epi_counted;
   if (WS_DBG) a.stamps = getenv("SX_WS_STAMPS") ? (unsigned long long*)strtoull(getenv("SX_WS_STAMPS"), nullptr, 0) : nullptr;   // diagnostic build only
   a.tiles_x = cdiv(a.W, TW);
   a.tiles_y = cdiv(a.H, TH);
@@ -587,6 +643,11 @@ static int ws_pick_tile(const ConvArgs& a, hipStream_t st) {
   if (a.RTot <= 32) {
     if constexpr (KCH > 4) return 1;
     else if constexpr (LIGHT) return launch_ws<KCH, TAPS, 1, 4, 2, 2, 4, VAR>(a, st);   // 32 ch x 128 px
+    else if constexpr (VAR == WS_DUAL && KCH == 2) {
+      static const int light2 = env_int("SX_WS_DUAL2", 1);
+      if (light2) return launch_ws<KCH, TAPS, 1, 4, 2, 2, 4, VAR>(a, st);
+      return launch_ws<KCH, TAPS, 2, 4, 1, 4, 4, VAR>(a, st);
+    }
     else return launch_ws<KCH, TAPS, 2, 4, 1, 4, 4, VAR>(a, st);                        // 32 ch x 256 px (16 rows)
   } else if (a.RTot <= 64) {
     // 64 input channels: 16-channel wave tiles (72 weight registers) fit two blocks per CU: 17.6 -> 15.9 us, with the
