@@ -319,7 +319,11 @@ def test_conv_wgrad_persistent_bf16(L, mode, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 8, 16), (3, 7, 5, 24), (2, 32, 16, 64)])
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 8, 16), (3, 7, 5, 24), (2, 32, 16, 64),
+                                      # shapes whose (sample, group) unit fits one block's registers: the backward is ONE launch
+                                      # (act_bwd_group_kernel: 1, 2 and 4 slots per thread, a partly filled block, 64-channel groups)
+                                      (3, 16, 8, 256), (2, 32, 16, 128), (2, 8, 8, 64), (2, 12, 10, 128), (1, 4, 4, 512),
+                                      (2, 64, 32, 64)])      # one size up: two launches again
 def test_groupnorm_silu_block_out_forward_backward(L, dtype, B, H, W, Cc):
     g = torch.Generator().manual_seed(Cc + H)
     G = min(8, Cc)

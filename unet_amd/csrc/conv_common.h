@@ -127,6 +127,13 @@ __device__ __forceinline__ void gn_stats_flush(const float* sm_stat, int tid, in
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
 enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3, WS_GATHER = 4 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
+// sx_conv_forward_gn_bwd_sums with the option to leave the sums to the one-launch GroupNorm backward of small levels
+// (conv_igemm.hip; `deferred` null = always form them)
+int conv_forward_gn_bwd_sums(int dtype, int mode, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,
+                             const void* packed, void* y, int y_ld, int gn_mode, const void* gn_y, int gn_y_ld,
+                             const void* gn_s, int gn_s_ld, const float* stats, int groups, float eps,
+                             const float* gamma, const float* beta, const float* film_g, const float* drop,
+                             float* sums, int* deferred, void* stream);
 // fp32 tensors, split-bf16 arithmetic (conv_x3.hip); var = WS_PLAIN or WS_CENTER; 1 = variant / shape not covered
 int conv_x3_dispatch(const ConvArgs& a, hipStream_t st, int var = WS_PLAIN);
 

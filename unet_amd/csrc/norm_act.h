@@ -54,6 +54,10 @@ inline int gn_param_grad_layout(GnGradArgs& A) {
 // dgamma[c] (+)= sum_b sums[b][c][0], dbeta[c] (+)= sum_b sums[b][c][1] for every descriptor, one launch per 32
 int gn_param_grad_multi(const GnGradDesc* descs, int n, int B, int accumulate, hipStream_t st);
 
+// true when sx_gn_silu_backward runs both phases of this shape in one launch (act_bwd_group_kernel): a producer of d_out then
+// need not form the sums
+bool gn_bwd_group_fused_ok(int B, int HW, int C, int groups);
+
 // Phase 1 of GroupNorm + SiLU backward alone (per-(sample, channel) sums; mode 0 or 2 of sx_gn_silu_backward): what a
 // producer of d_out runs when it could not fuse the sums into its own epilogue.
 int gn_bwd_reduce_only(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y, int y_ld, const float* stats,

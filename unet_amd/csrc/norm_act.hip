@@ -277,6 +277,140 @@ __global__ __launch_bounds__(256) void act_bwd_reduce_kernel(ActArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- backward, both phases in ONE launch (small levels)
+// A GroupNorm group of one sample is self-contained: the element-wise phase needs the group's two means, the per-channel sums
+// stay inside the group.  Where HW x C/G elements fit the registers of one block (<= 8192: the 32x16 and 16x8 levels of
+// cfg A), block (b, g) reads Y, dO (and S) ONCE, forms the sums (wave butterfly + one LDS exchange), stores them -- plain
+// stores, this block owns (b, channels of g): no atomics, no zeroing needed -- and applies the gradient from registers.
+// Replaces a reduce + apply pair (2 launches of 7-14 us on the dispatch floor, Y and dO read twice).
+// Grid (B, G): block id & 7 = b & 7, so the groups of a sample share an XCD's L2 (they read the same 128-byte lines).
+// A thread owns NSLOT 8-channel pieces with ONE piece index (256 % pieces-per-pixel == 0): its coefficients are registers.
+template <typename T, int MODE, int NSLOT>
+__global__ __launch_bounds__(256) void act_bwd_group_kernel(ActArgs a) {
+  constexpr int NS = MODE ? 4 : 2;
+  __shared__ float red[4][NS][64];       // [wave][sum][channel of the group]
+  __shared__ float tot[NS][64];
+  const int b = blockIdx.x, grp = blockIdx.y;
+  const int cpg = a.C / a.G, ppp = cpg >> 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int piece = tid % ppp;
+  const int c0 = grp * cpg + piece * 8;
+  const float inv_n = 1.0f / ((float)cpg * (float)a.HW);
+  const float* stp = a.stats + ((int64_t)b * a.G + grp) * 2;
+  const float mean = stp[0] * inv_n;
+  const float rs = rsqrtf(fmaxf(stp[1] * inv_n - mean * mean, 0.f) + a.eps), mr = mean * rs;
+  float ga[8], be[8], fac[8], drp[MODE == 2 ? 8 : 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ga[e] = a.gamma[c0 + e];
+    be[e] = a.beta[c0 + e];
+    float f = 1.f;
+    if (MODE) {
+      const float dr = a.drop ? a.drop[(int64_t)b * a.C + c0 + e] : 1.f;
+      if (a.gf) f *= a.gf[(int64_t)b * a.C + c0 + e];
+      f *= dr;
+      if (MODE == 2) drp[e] = dr;
+    }
+    fac[e] = f;
+  }
+  const int n_slots = a.HW * ppp;
+  const T* Y = reinterpret_cast<const T*>(a.Y);
+  const T* R = reinterpret_cast<const T*>(a.R);
+  const T* dO = reinterpret_cast<const T*>(a.dO);
+  f32x8 y[NSLOT], g[NSLOT], r[MODE ? NSLOT : 1];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int q = tid + k * 256;
+    if (q < n_slots) {
+      const int64_t pix = (int64_t)b * a.HW + q / ppp;
+      y[k] = load8(Y + pix * a.y_ld + c0);
+      g[k] = load8(dO + pix * a.do_ld + c0);
+      if (MODE) r[k] = load8(R + pix * a.r_ld + c0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { y[k].v[e] = 0.f; g[k].v[e] = 0.f; if (MODE) r[k].v[e] = 0.f; }
+    }
+  }
+  float acc[NS][8];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  // phase 1; afterwards g holds da = dO * gf * drop and (r in mode 1 / 2, g's partner otherwise) holds dz = da * silu'(z)
+  f32x8 dzs[MODE ? 1 : NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float nh = y[k].v[e] * rs - mr;
+      const float z = nh * ga[e] + be[e];
+      const float sg = sigmoidf_(z);
+      const float gq = g[k].v[e];                 // zero outside the sample: contributes nothing
+      const float dz = gq * (sg * (1.0f + z * (1.0f - sg)));
+      acc[0][e] += dz * nh;
+      acc[1][e] += dz;
+      if (MODE) {
+        const float rr = MODE == 2 ? (z * sg + r[k].v[e]) * drp[e] : r[k].v[e];
+        acc[2][e] += gq * rr;
+        acc[3][e] += gq;
+        r[k].v[e] = dz * fac[e];
+        g[k].v[e] = gq * fac[e];
+      } else {
+        dzs[k].v[e] = dz;
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[0][e] *= fac[e]; acc[1][e] *= fac[e]; }
+  // lanes with the same piece index: butterfly over the lane bits above log2(ppp)
+  // (mask loop outside: the NS x 8 exchanges of one step are independent and pipeline; the other nesting ran 32 serial chains)
+  for (int m = 32; m >= ppp; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[i][e] += __shfl_xor(acc[i][e], m, 64);
+  }
+  if (lane < ppp) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][i][piece * 8 + e] = acc[i][e];
+  }
+  __syncthreads();
+  for (int o = tid; o < NS * cpg; o += 256) {
+    const int i = o / cpg, c = o - i * cpg;
+    const float t = (red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c]);
+    // gamma-weighted for the group means below (one parallel load per thread here; a global load inside the loop over the
+    // group's channels would cost one memory latency per trip)
+    tot[i][c] = i < 2 ? t * a.gamma[grp * cpg + c] : t;
+    a.sums[((int64_t)b * a.C + grp * cpg + c) * 4 + i] = t;
+  }
+  __syncthreads();
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = 0; c < cpg; ++c) {
+    m1 += tot[1][c];
+    m2 += tot[0][c];
+  }
+  m1 *= inv_n; m2 *= inv_n;
+  T* dY = reinterpret_cast<T*>(a.out0);
+  T* dR = reinterpret_cast<T*>(a.out1);
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int q = tid + k * 256;
+    if (q < n_slots) {
+      const int64_t pix = (int64_t)b * a.HW + q / ppp;
+      f32x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float nh = y[k].v[e] * rs - mr;
+        const float dz = MODE ? r[k].v[e] : dzs[k].v[e];
+        o.v[e] = rs * (ga[e] * dz - m1 - nh * m2);
+      }
+      store8(dY + pix * a.o0_ld + c0, o);
+      if (MODE && dR) store8(dR + pix * a.o1_ld + c0, g[k]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- backward, phase 2
 // dY = rstd * (gamma*dz - mean_g(gamma*dz) - n_hat * mean_g(gamma*dz*n_hat)) ; dR = dO*gf*drop (optional)
 template <typename T, int MODE, int CMAX>
@@ -379,6 +513,33 @@ static dim3 act_grid(ActArgs& a, int target = 2048) {
   a.pix_per_block = cdiv(a.HW, chunks);
   chunks = cdiv(a.HW, a.pix_per_block);
   return dim3(chunks, a.B);
+}
+
+// slots per thread of act_bwd_group_kernel for this shape, 0 = not covered (the two-launch path runs)
+static int act_group_slots(const ActArgs& a) {
+  static const int on = env_int("SX_GN_GROUP_FUSED", 1);       // A/B knob
+  if (!on) return 0;
+  const int cpg = a.C / a.G;
+  if (cpg % 8 || cpg > 64) return 0;
+  const int ppp = cpg / 8;
+  if (ppp & (ppp - 1)) return 0;
+  const int64_t n_slots = (int64_t)a.HW * ppp;
+  if (n_slots > 1024) return 0;
+  return n_slots <= 256 ? 1 : (n_slots <= 512 ? 2 : 4);
+}
+
+template <typename T, int MODE>
+static void act_group_launch(int nslot, dim3 grid, hipStream_t st, const ActArgs& a) {
+  if (nslot == 1) hipLaunchKernelGGL((act_bwd_group_kernel<T, MODE, 1>), grid, dim3(256), 0, st, a);
+  else if (nslot == 2) hipLaunchKernelGGL((act_bwd_group_kernel<T, MODE, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((act_bwd_group_kernel<T, MODE, 4>), grid, dim3(256), 0, st, a);
+}
+
+bool gn_bwd_group_fused_ok(int B, int HW, int C, int groups) {
+  ActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.HW = HW; a.C = C; a.G = groups;
+  return groups > 0 && C % groups == 0 && C % 8 == 0 && act_group_slots(a) > 0;
 }
 
 }  // namespace sx
@@ -516,6 +677,26 @@ extern "C" int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, in
   SX_TRY(act_check(a, "sx_gn_silu_backward"));
   dim3 grid = act_grid(a);
   hipStream_t st = (hipStream_t)stream;
+  if (const int nslot = sums_ready ? 0 : act_group_slots(a)) {
+    // small levels: both phases in one launch, one block per (sample, group)
+    const dim3 gg(B, groups);
+    if (dtype == SX_BF16) {
+      if (mode == 2) act_group_launch<bf16, 2>(nslot, gg, st, a);
+      else if (mode) act_group_launch<bf16, 1>(nslot, gg, st, a);
+      else act_group_launch<bf16, 0>(nslot, gg, st, a);
+    } else {
+      if (mode == 2) act_group_launch<float, 2>(nslot, gg, st, a);
+      else if (mode) act_group_launch<float, 1>(nslot, gg, st, a);
+      else act_group_launch<float, 0>(nslot, gg, st, a);
+    }
+    SX_LAUNCH_CHECK("gn_bwd_group");
+    if (dgamma && dbeta) {
+      GnGradDesc d;
+      d.sums = sums; d.dgamma = dgamma; d.dbeta = dbeta; d.C = C; d.blk0 = 0; d.nb = 0; d.stride = 4;
+      SX_TRY(gn_param_grad_multi(&d, 1, B, accumulate, st));
+    }
+    return SX_OK;
+  }
   // the block-output pass (four sums, three tensors) pays more per block for its combine: half as many blocks
   dim3 grid_r = mode ? act_grid(a, 1024) : grid;
   if (!sums_ready) {

@@ -418,11 +418,13 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
     SX_TRY(wq.add(SX_CONV3, b.H, b.W, b.C, b.C, b.C, b.C, at(ws, b.dY), b.C, at(ws, b.A1), b.C, b.H, b.W, grads[b.pidx + 3]));
   }
   // dA1 = W2^T (*) dY, with phase 1 of GroupNorm-1's backward (per-(sample, channel) sums) in the convolution's epilogue
-  SX_TRY(sx_conv_forward_gn_bwd_sums(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, at(wpack, b.w2d), at(ws, b.dA1), b.C,
-                                     0, at(ws, b.Y1), b.C, nullptr, 0, (const float*)at(ws, b.st1), b.G, GN_EPS, g1, be1,
-                                     nullptr, nullptr, (float*)at(ws, b.sums1), st));
+  // (small levels: the sums are left to the one-launch backward below, `deferred`)
+  int deferred = 0;
+  SX_TRY(conv_forward_gn_bwd_sums(dt, SX_CONV3, B, b.H, b.W, b.C, b.C, at(ws, b.dY), b.C, at(wpack, b.w2d), at(ws, b.dA1), b.C,
+                                  0, at(ws, b.Y1), b.C, nullptr, 0, (const float*)at(ws, b.st1), b.G, GN_EPS, g1, be1,
+                                  nullptr, nullptr, (float*)at(ws, b.sums1), &deferred, st));
   // through SiLU / GN1, element-wise phase (its own buffer: the deferred weight-gradient launch still reads dY)
-  SX_TRY(sx_gn_silu_backward(dt, 0 | SX_GN_BWD_SUMS_READY, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
+  SX_TRY(sx_gn_silu_backward(dt, deferred ? 0 : SX_GN_BWD_SUMS_READY, B, HW, b.C, b.G, GN_EPS, at(ws, b.Y1), b.C, (const float*)at(ws, b.st1), g1, be1,
                              at(ws, b.dA1), b.C, nullptr, 0, nullptr, nullptr, (float*)at(ws, b.sums1), at(ws, b.dY1), 2 * b.C,
                              nullptr, 0, nullptr, nullptr, acc, st));
   if (wg) wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
