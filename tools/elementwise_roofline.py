@@ -57,6 +57,14 @@ for pos, name in step:
             byt, what = 3 * T[lvl], f"GN+SiLU bwd, apply     L{lvl}: read Y,dO, write dY"
             bstate = 0
             bblk += 1
+    elif k == "act_bwd_group":
+        # both phases of a backward in one launch (small levels): block output (state 0) or GroupNorm-1 (state 2)
+        lvl = LEVELS[bblk]
+        if bstate == 0: byt, what, bstate = 5 * T[lvl], f"block out bwd, 1 launch L{lvl}: read Y,dO,S, write dY,dR", 2
+        else:
+            byt, what = 3 * T[lvl], f"GN+SiLU bwd, 1 launch  L{lvl}: read Y,dO, write dY"
+            bstate = 0
+            bblk += 1
     elif k in ("maxpool_bwd_add", "maxpool_bwd_add_idx"):
         lvl = [2, 1, 0][pool_b]; pool_b += 1
         if k.endswith("idx"): byt, what = 2.375 * T[lvl], f"max-pool bwd + skip    L{lvl}: read positions,dskip,dP, write dO"

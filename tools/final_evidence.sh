@@ -7,6 +7,7 @@ bash tools/prof_step.sh $tag || exit 1
 PROF_ARGS="--dtype fp32" bash tools/prof_step.sh ${tag}_fp32 || exit 1
 bash tools/prof_cmd.sh ${tag}_cfg5 25 tools/cfg5_bench.py 32 20 bf16 || exit 1
 timeout -k 10 200 python tools/conv_layers.py > gpurun_out/${tag}_conv_layers.txt 2>&1 || exit 1
+CFG=5 timeout -k 10 200 python tools/conv_layers.py > gpurun_out/${tag}_conv_layers_cfg5.txt 2>&1 || exit 1
 timeout -k 10 200 python tools/wgrad_bench.py > gpurun_out/${tag}_wgrad_layers.txt 2>&1 || exit 1
 CFG=5 timeout -k 10 200 python tools/wgrad_bench.py 32 > gpurun_out/${tag}_wgrad_layers_cfg5.txt 2>&1 || exit 1
 bash tools/prof_pmc.sh ${tag}_pmc_f FETCH_SIZE bench.py $B --steps 5 --warmup 3 || exit 1
