@@ -200,7 +200,11 @@ int sx_block_out_pool_idx_forward(int dtype, int B, int H, int W, int C, int gro
                                   const float* film_g, const float* film_b, const float* drop, void* out, int out_ld,
                                   void* r_out, int r_ld, void* pool, int pool_ld, void* pool_idx, int idx_ld, void* stream);
 /* mode | SX_GN_BWD_SUMS_READY: `sums` entries were already accumulated by the producer of d_out
- * (sx_conv_forward_gn_bwd_sums, sx_maxpool2_backward_gn_sums): only the element-wise phase runs. */
+ * (sx_conv_forward_gn_bwd_sums, sx_maxpool2_backward_gn_sums): only the element-wise phase runs.
+ * Without the flag, shapes whose (sample, group) unit holds at most 8192 elements (HW * C / groups; C / groups a multiple of
+ * 8 and a power-of-two number of 8-channel pieces) run both phases in ONE launch: one block per (sample, group) reads y, d_out
+ * (and r) once, WRITES its sums entries (plain stores, no atomics) and applies the gradient from registers; larger shapes run
+ * the two-launch form, which ACCUMULATES into `sums` (caller zeroes).  Zeroing `sums` first is correct for both. */
 #define SX_GN_BWD_SUMS_READY 4
 int sx_gn_silu_backward(int dtype, int mode, int B, int HW, int C, int groups, float eps, const void* y,
                         int y_ld, const float* stats, const float* gamma, const float* beta,
