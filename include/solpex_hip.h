@@ -288,6 +288,19 @@ int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, const void* 
                              int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
                              void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
                              void* stream);
+/* The same call, also forming the output head's bias gradient on the way out (models.py:203, `out.bias`): bias_sums
+ * [SX_HEAD_BIAS_SLOTS][C] fp32 (caller-zeroed; sx_unet_view(SX_T_HEAD_BIAS_SUMS) inside a network workspace) += per-channel
+ * sums of d_pred as stored, spread over the slots; *bias_done (HOST int, nullable) = 1 when this configuration's kernels took
+ * them (single scale, grad_ds 2, C <= 8, 8-wide rows), else 0 and bias_sums is untouched.  With 1, pass
+ * SX_BWD_HEAD_BIAS_READY to sx_unet_decode_backward, which then skips its own pass over d_pred.  No sx_loss_ev_l1 after it:
+ * that call adds to d_pred. */
+#define SX_HEAD_BIAS_SLOTS 64
+int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld,
+                                  const float* target, const float* mask, const float* w, const float* cw,
+                                  int base_kind, float huber_beta, float lam_w, float lam_grad, int grad_magnitude,
+                                  int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
+                                  void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
+                                  float* bias_sums, int* bias_done, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Output normalizers and masked metrics (data.py:96-110,139-143,157-163,187-223; losses.py:226-253).
@@ -385,6 +398,8 @@ typedef enum sx_unet_tensor {
   SX_T_DSKIP = 5,      /* gradient w.r.t. skip `index` (written by decode backward) */
   SX_T_DBOTTLENECK = 6,
   SX_T_FILM_DPARAMS = 7, /* fp32 [B][P]: d loss / d params, accumulated by both backward halves */
+  SX_T_HEAD_BIAS_SUMS = 9, /* fp32 [SX_HEAD_BIAS_SLOTS][out_ch]: the head's bias-gradient partial sums (zeroed with the backward
+                              sums; sx_loss_forward_backward_bias may fill them before sx_unet_decode_backward)           */
   SX_T_DINPUT = 8        /* gradient w.r.t. the input image x (layout of INPUT), written by sx_unet_encode_backward
                             when SX_BWD_INPUT_GRAD is set */
 } sx_unet_tensor;
@@ -414,6 +429,12 @@ int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const 
 #define SX_BWD_NO_DPARAMS       64 /* skip FILM_DPARAMS (the gradient w.r.t. the FiLM inputs): a training step does not read it */
 #define SX_BWD_INPUT_GRAD      128 /* sx_unet_encode_backward: also back-propagate to the input image (SX_T_DINPUT); the
                                       reference gets it from autograd when x.requires_grad (models.py:205) */
+#define SX_BWD_SUMS_CLEARED    256 /* sx_unet_decode_backward (with SX_BWD_DEFER_FILM): the backward sums / bias scratch of this workspace
+                                      are already zero because sx_unet_encode ran on it SINCE the last backward with use_film == 2 and
+                                      FiLM parameters (its FiLM launch clears them together with the statistics): no memset dispatch.
+                                      Ignored (the memset runs) for any other descriptor.                                          */
+#define SX_BWD_HEAD_BIAS_READY 512 /* sx_unet_decode_backward (with SX_BWD_SUMS_CLEARED): SX_T_HEAD_BIAS_SUMS already holds the sums of
+                                      d_pred (sx_loss_forward_backward_bias): no channel-sum launch                                */
 #define SX_BWD_ONLY_BOTTLENECK  16 /* sx_unet_encode_backward only: back-propagate the bottleneck block and finish ITS convolution
                                       weight gradients (bot.net.{0,3}.weight, bot.shortcut.weight), then return ...            */
 #define SX_BWD_AFTER_BOTTLENECK 32 /* ... and a second call with this flag does everything else (the encoder levels, every

@@ -107,6 +107,17 @@ class UNetSession:
         self._views[key] = t
         return t.view(t.shape) if fresh else t
 
+    def head_bias_sums(self):
+        """fp32 [SX_HEAD_BIAS_SLOTS * out_ch] slots of the output head's bias gradient (SX_T_HEAD_BIAS_SUMS)."""
+        v = self._views.get("head_bias")
+        if v is None:
+            vw = L.View()
+            L.check(self.lib.sx_unet_view(C.byref(self.desc), L.SX_T_HEAD_BIAS_SUMS, 0, C.byref(vw)))
+            n = L.SX_HEAD_BIAS_SLOTS * vw.C
+            v = self.ws[vw.offset_bytes: vw.offset_bytes + 4 * n].view(torch.float32)
+            self._views["head_bias"] = v
+        return v
+
     # ------------------------------------------------------------------ pointer tables
     def set_params(self, tensors):
         key = tuple(t.data_ptr() for t in tensors)

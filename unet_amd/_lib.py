@@ -19,6 +19,8 @@ SX_ERR_INVALID, SX_ERR_UNSUPPORTED, SX_ERR_HIP = -1, -2, -3
  SX_T_FILM_DPARAMS, SX_T_DINPUT) = range(9)
 SX_BWD_WEIGHT_GRADS, SX_BWD_ACCUMULATE, SX_BWD_ZERO_DPARAMS, SX_BWD_DEFER_FILM = 1, 2, 4, 8
 SX_BWD_ONLY_BOTTLENECK, SX_BWD_AFTER_BOTTLENECK, SX_BWD_NO_DPARAMS, SX_BWD_INPUT_GRAD = 16, 32, 64, 128
+SX_BWD_SUMS_CLEARED, SX_BWD_HEAD_BIAS_READY = 256, 512
+SX_T_HEAD_BIAS_SUMS, SX_HEAD_BIAS_SLOTS = 9, 64
 SX_NORM_LOG, SX_NORM_LINEAR, SX_NORM_SYMLOG = 0, 1, 2
 SX_WGRAD_STATIC_BYTES = 32 << 20
 SX_GN_BWD_SUMS_READY = 4
@@ -75,6 +77,8 @@ SIGNATURES = {
     "sx_loss_prepare": (_i, [_i, _i, _i, _i, _p, _p, _i, _i, _f, _p, _p, _p]),
     "sx_loss_forward_backward": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i, _i, _f, _i,
                                       _p, _p, _p, _p, _i, _f, _p]),
+    "sx_loss_forward_backward_bias": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i, _i, _f, _i,
+                                           _p, _p, _p, _p, _i, _f, _p, _p, _p]),
     "sx_norm_apply": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sx_masked_err_sums": (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sx_loss_ev_l1": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _i, _f, _p]),

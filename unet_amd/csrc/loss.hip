@@ -319,6 +319,7 @@ struct FuseArgs {
   int B, C, H, W, k;
   int kind; float beta, lam_w;
   const float* den;
+  float* bias_sums;   // grad_out (fast instance) only, nullable: [SX_HEAD_BIAS_SLOTS][C] fp32, += per-channel sums of d_pred as stored
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_;
@@ -484,6 +485,10 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
   const float inv = 1.0f / (float)(k * k);
   T* out = reinterpret_cast<T*>(a.dpred);
   const int64_t n = (int64_t)a.B * gh * gw;
+  float bsum[MC];                 // head bias gradient: this thread's share (fast instance; the host checks n % 256 == 0 and one
+  int bcg = 0;                    // item per thread at most, so a block works on one channel group)
+#pragma unroll
+  for (int c = 0; c < MC; ++c) bsum[c] = 0.f;
   GRID_STRIDE(ii, n * CG) {
     const int cg = FAST ? (int)(ii / n) : 0;
     const int c0 = cg * MC;
@@ -522,6 +527,9 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
         T* dst = out + ((int64_t)b * hw + px) * 8 + c0;
         if constexpr (MC == 4) { store4(dst, o0); store4(dst + 8, o1); }
         else { store2(dst, f32x2_{o0[0], o0[1]}); store2(dst + 8, f32x2_{o1[0], o1[1]}); }
+#pragma unroll
+        for (int c = 0; c < MC; ++c) bsum[c] += (float)(T)o0[c] + (float)(T)o1[c];      // the values as stored (what channel_sum would read)
+        bcg = cg;
       }
     } else {
       for (int dy = 0; dy < k; ++dy)
@@ -544,6 +552,22 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
             store8(dst + c0, o);
           }
         }
+    }
+  }
+  if constexpr (FAST) {
+    if (a.bias_sums) {          // wave butterfly -> LDS -> one atomic per channel and block, spread over SX_HEAD_BIAS_SLOTS lines
+      __shared__ float bred[4][MC];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        float v = bsum[c];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) bred[threadIdx.x >> 6][c] = v;
+      }
+      __syncthreads();
+      const int cgb = __shfl(bcg, 0, 64);      // uniform per block (see above); blocks past the last item add zeros to group 0
+      if (threadIdx.x < MC && cgb * MC + (int)threadIdx.x < a.C)
+        atomicAdd(a.bias_sums + (blockIdx.x % SX_HEAD_BIAS_SLOTS) * a.C + cgb * MC + threadIdx.x,
+                  (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]));
     }
   }
 }
@@ -676,6 +700,18 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
                                         int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
                                         void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
                                         void* stream) {
+  return sx_loss_forward_backward_bias(dtype, B, C, H, W, pred, pred_ld, target, mask, w, cw, base_kind, huber_beta, lam_w, lam_grad,
+                                       grad_magnitude, grad_kind, multiscale, ms_weight, grad_ds, den, workspace, out, d_pred,
+                                       dpred_ld, grad_scale, nullptr, nullptr, stream);
+}
+
+extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int W, const void* pred, int pred_ld,
+                                             const float* target, const float* mask, const float* w, const float* cw,
+                                             int base_kind, float huber_beta, float lam_w, float lam_grad, int grad_magnitude,
+                                             int grad_kind, int multiscale, float ms_weight, int grad_ds, const float* den,
+                                             void* workspace, float* out, void* d_pred, int dpred_ld, float grad_scale,
+                                             float* bias_sums, int* bias_done, void* stream) {
+  if (bias_done) *bias_done = 0;
   SX_REQUIRE(pred && target && mask && den && workspace && out, "sx_loss_forward_backward: null pointer");
   if (px_kind(base_kind, "sx_loss_forward_backward") < 0 || px_kind(grad_kind, "sx_loss_forward_backward") < 0) return SX_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -716,6 +752,11 @@ extern "C" int sx_loss_forward_backward(int dtype, int B, int C, int H, int W, c
     sa.den = den; sa.cgl = lam_grad;
     hipLaunchKernelGGL(sobel_fwd_kernel, dim3(gsz(ng)), dim3(256), 0, st, sa);
     if (want_grad) {
+      // head bias gradient on the way out (fast instance, block-uniform channel group, one item per thread at most)
+      if (bias_sums && fast && nwin % 256 == 0 && FUSE_CG * nwin <= (int64_t)2048 * 256) {
+        fa.bias_sums = bias_sums;
+        if (bias_done) *bias_done = 1;
+      }
       SX_FUSE_LAUNCH(grad_out_kernel, fa, f);          // block 0 also finishes the loss value
     } else {
       hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);

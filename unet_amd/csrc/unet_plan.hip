@@ -153,7 +153,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   for (auto& b : p.blk) { b.sums1 = take((int64_t)B * b.C * 4 * 4); b.sums2 = take((int64_t)B * b.C * 4 * 4); }
   p.sums_end = off;
   for (int j = 0; j < D; ++j) p.bias_scr[j] = take((int64_t)p.C[D - 1 - j] * 4);
-  p.head_bias_scr = take((int64_t)p.out_pad * 4);
+  p.head_bias_scr = take((int64_t)SX_HEAD_BIAS_SLOTS * p.out_pad * 4);      // [slot][out_ch]: channel_sum fills slot 0, the loss kernel all
   p.bwd_zero_end = off;
   p.dparams = take((int64_t)B * std::max(1, d.P) * 4);
   // wgrad slabs: every layer of a backward half keeps its own slab until the fused reduction at the end of the half
@@ -285,9 +285,9 @@ struct WgQueue {
     gn.push_back(d);
   }
   // bias gradient: channel sums accumulated in workspace scratch (zeroed with the backward sums), copied / added here
-  void add_bias(const float* scratch, float* db, int C) {
+  void add_bias(const float* scratch, float* db, int C, int slots = 1) {
     GnGradDesc d;
-    d.sums = scratch; d.dgamma = db; d.dbeta = nullptr; d.C = C; d.blk0 = 0; d.nb = 1; d.stride = 1;
+    d.sums = scratch; d.dgamma = db; d.dbeta = nullptr; d.C = C; d.blk0 = 0; d.nb = slots; d.stride = 1;
     gn.push_back(d);
   }
   int flush() {
@@ -491,6 +491,7 @@ extern "C" int sx_unet_view(const sx_unet_desc* d, int which, int index, sx_view
       set(p.dcat[index] + (int64_t)p.C[index] * p.esz, 2 * p.C[index], p.C[index], index); break;
     case SX_T_DBOTTLENECK: set(p.blk[D].dO, p.C[D], p.C[D], D); break;
     case SX_T_DINPUT: set(p.blk[0].dX, p.in_pad, d->in_ch, 0); break;
+    case SX_T_HEAD_BIAS_SUMS: out->offset_bytes = p.head_bias_scr; out->ld = d->out_ch; out->C = d->out_ch; out->H = 1; out->W = SX_HEAD_BIAS_SLOTS; break;
     case SX_T_FILM_DPARAMS: out->offset_bytes = p.dparams; out->ld = d->P; out->C = d->P; out->H = 1; out->W = 1; break;
     default: set_error("sx_unet_view: unknown tensor %d", which); return SX_ERR_INVALID;
   }
@@ -546,8 +547,10 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
   const int dt = d->dtype, B = d->B, D = p.depth;
   // clear the encoder's GN statistics (blocks 0..D are laid out first).  use_film == 2 pairs every decode with the encode
   // before it: the decoder's statistics are cleared here too, and by the FiLM launch itself instead of a memset dispatch
-  const int64_t zb0 = p.blk[0].st1, zb1 = d->use_film == 2 ? p.stats_end : p.blk[D + 1].st1;
+  // ... and, laid out right behind them, the backward pass's sums and bias scratch (SX_BWD_SUMS_CLEARED: the backward of a
+  // training step then has no memset dispatch either)
   const bool film_clears = film && d->use_film == 2;
+  const int64_t zb0 = p.blk[0].st1, zb1 = d->use_film == 2 ? (film_clears ? p.bwd_zero_end : p.stats_end) : p.blk[D + 1].st1;
   if (!film_clears) {
     hipError_t e = hipMemsetAsync(at(ws, zb0), 0, (size_t)(zb1 - zb0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
@@ -611,13 +614,17 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   const bool film = d->use_film != 0;
   hipStream_t st = (hipStream_t)stream;
   const int dt = d->dtype, B = d->B, D = p.depth;
+  // SX_BWD_SUMS_CLEARED: the caller's promise that sx_unet_encode of THIS step (use_film == 2, FiLM on) cleared them
+  const bool cleared = (flags & SX_BWD_SUMS_CLEARED) && d->use_film == 2 && film_params;
   {
     // decoder sums, bias scratch and (optionally) dparams are contiguous: one memset. SX_BWD_DEFER_FILM promises that
     // sx_unet_encode_backward follows on this workspace, so the encoder's sums (laid out just before) are cleared too
-    const int64_t s0 = (flags & SX_BWD_DEFER_FILM) ? p.blk[0].sums1 : p.blk[D + 1].sums1;
+    const int64_t s0 = cleared ? p.bwd_zero_end : ((flags & SX_BWD_DEFER_FILM) ? p.blk[0].sums1 : p.blk[D + 1].sums1);
     const int64_t s1 = (flags & SX_BWD_ZERO_DPARAMS) ? p.dparams + (int64_t)align_up((size_t)B * std::max(1, d->P) * 4, 256) : p.bwd_zero_end;
-    hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
-    if (e != hipSuccess) return hip_fail(e, "memset(sums)");
+    if (s1 > s0) {
+      hipError_t e = hipMemsetAsync(at(ws, s0), 0, (size_t)(s1 - s0), st);
+      if (e != hipSuccess) return hip_fail(e, "memset(sums)");
+    }
   }
   WgQueue wq(p, ws, acc, st);
   // head
@@ -625,8 +632,9 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
   if (wg) {
     SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
                   at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
-    SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), stream));
-    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch);
+    if (!(cleared && (flags & SX_BWD_HEAD_BIAS_READY)))
+      SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), stream));
+    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch, SX_HEAD_BIAS_SLOTS);
   }
   SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], at(ws, p.dpred), p.out_pad, d->H, d->W, at(wpack, p.headd),
                          nullptr, at(ws, last.dO), p.C[0], d->H, d->W, 0, nullptr, 0, stream));
@@ -715,7 +723,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
       wq.add_gn((const float*)at(ws, b.sums1), grads[b.pidx + 1], grads[b.pidx + 2], b.C);
     }
   if (wg && (flags & SX_BWD_DEFER_FILM)) {       // ... and so are the head / transposed-conv bias sums
-    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch);
+    wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch, SX_HEAD_BIAS_SLOTS);
     for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
   }
   const int ngen = (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1;

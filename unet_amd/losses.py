@@ -83,13 +83,20 @@ def loss_prepare(bufs, B, Cc, H, W, mask, w, multiscale, grad_ds, lam_grad):
 
 
 def loss_forward_backward(bufs, sx_dtype, B, Cc, H, W, pred, pred_ld, target, mask, w, cw, base, huber_beta, lam_w, lam_grad,
-                          grad_mode, grad_base, multiscale, ms_weight, grad_ds, d_pred, dpred_ld, grad_scale=1.0, out=None):
-    L.check(L.lib().sx_loss_forward_backward(
+                          grad_mode, grad_base, multiscale, ms_weight, grad_ds, d_pred, dpred_ld, grad_scale=1.0, out=None,
+                          bias_sums=None):
+    """`bias_sums` (optional, zeroed [SX_HEAD_BIAS_SLOTS][C] fp32): also form the output head's bias gradient from d_pred;
+    returns True when the kernels took it (then nothing may add to d_pred afterwards)."""
+    import ctypes
+    done = ctypes.c_int(0)
+    L.check(L.lib().sx_loss_forward_backward_bias(
         sx_dtype, B, Cc, H, W, L.ptr(pred), pred_ld, L.ptr(target), L.ptr(mask), L.ptr(w), L.ptr(cw),
         L.PX_KINDS[base], float(huber_beta), float(lam_w), float(lam_grad), 1 if grad_mode == "magnitude" else 0,
         L.PX_KINDS[grad_base], int(multiscale), float(ms_weight), int(grad_ds), L.ptr(bufs.den), L.ptr(bufs.ws),
-        L.ptr(bufs.out if out is None else out), L.ptr(d_pred), dpred_ld, float(grad_scale), L.stream_ptr()),
+        L.ptr(bufs.out if out is None else out), L.ptr(d_pred), dpred_ld, float(grad_scale),
+        L.ptr(bias_sums), ctypes.cast(ctypes.byref(done), ctypes.c_void_p) if bias_sums is not None else None, L.stream_ptr()),
         "sx_loss_forward_backward")
+    return bool(done.value)
 
 
 class _LossFn(torch.autograd.Function):

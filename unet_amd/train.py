@@ -118,6 +118,7 @@ class TrainEngine:
             self.loss_opts.update(loss_opts)
         # optional physical-space L1 term of the training loss (reference: solpex/train.py:200-205)
         self.lam_ev = float(lam_ev or 0.0)
+        self._head_bias_ready = False
         self._ev_table = None
         if self.lam_ev > 0:
             if norm is None:
@@ -197,9 +198,13 @@ class TrainEngine:
         if self.nlog >= self.log.shape[0]:
             self.log = torch.cat([self.log, torch.zeros_like(self.log)])
         row = self.log[self.nlog]                       # [loss, sum|p-t|*m, sum m (global), sum m (local)]
-        loss_forward_backward(bufs, self.sx_dtype, B, Cc, H, W, pred, ld, tgt, m, self.w_map, self.cw, o["base"],
-                              o["huber_beta"], o["lam_w"], o["lam_grad"], o["grad_mode"], o["grad_base"], o["multiscale"],
-                              o["ms_weight"], o["grad_ds"], dpred, ld, grad_scale, out=row)
+        # the head's bias gradient rides on the loss's gradient kernel when this step's encode cleared its slots (FiLM on) and
+        # nothing adds to d(pred) afterwards (lam_ev)
+        bias_sums = sess.head_bias_sums() if (want_grad and sess.use_film and not self.lam_ev > 0) else None
+        self._head_bias_ready = loss_forward_backward(
+            bufs, self.sx_dtype, B, Cc, H, W, pred, ld, tgt, m, self.w_map, self.cw, o["base"],
+            o["huber_beta"], o["lam_w"], o["lam_grad"], o["grad_mode"], o["grad_base"], o["multiscale"],
+            o["ms_weight"], o["grad_ds"], dpred, ld, grad_scale, out=row, bias_sums=bias_sums)
         if self.lam_ev > 0 and want_grad:
             # training only (the reference's validation loss has no lam_ev term, train.py:262-276); den[0] = sum(mask), global under DP
             L.check(L.lib().sx_loss_ev_l1(self.sx_dtype, B, Cc, H, W, L.ptr(pred), ld, L.ptr(tgt), L.ptr(m), *self._ev_table.c_args(),
@@ -224,9 +229,10 @@ class TrainEngine:
         sess.encode(x, fp)
         sess.decode(fp, drop_table)
         out = self._loss_end(sess, bufs, y, begun, lg, True, 1.0 / max(int(grad_accum_steps), 1))
-        flags = (L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | L.SX_BWD_NO_DPARAMS |
+        # (sessions are film_shared: with FiLM on, this step's encode cleared the backward sums with the statistics)
+        flags = (L.SX_BWD_WEIGHT_GRADS | L.SX_BWD_DEFER_FILM | L.SX_BWD_NO_DPARAMS | L.SX_BWD_SUMS_CLEARED |
                  (L.SX_BWD_ACCUMULATE if self.accum > 0 else 0))
-        sess.decode_backward(fp, drop_table, flags)
+        sess.decode_backward(fp, drop_table, flags | (L.SX_BWD_HEAD_BIAS_READY if self._head_bias_ready else 0))
         h_dec = None
         closing = step_now and (self.accum + 1 >= max(int(grad_accum_steps), 1))
         if self.dp and closing:
