@@ -616,6 +616,43 @@ def test_loss_bf16_nhwc_prediction(L, golden):
     assert rel_err(pd.grad.float().cpu(), pr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("tdtype", [torch.bfloat16, torch.float32])
+def test_loss_forms_the_head_bias_gradient_on_the_way_out(L, tdtype):
+    """sx_loss_forward_backward_bias: the slots sum to the per-channel sums of d_pred as stored, the gradient itself is the plain
+    call's; configurations its kernels do not cover report 0 and leave the slots alone."""
+    from unet_amd.losses import LossBuffers, loss_prepare, loss_forward_backward
+    g = torch.Generator().manual_seed(11)
+    B, Cc, H, W = 8, 8, 32, 16
+    sx = 1 if tdtype == torch.bfloat16 else 0
+    pred = torch.randn(B, H, W, 8, generator=g).to(tdtype).cuda()
+    target = torch.randn(B, Cc, H, W, generator=g).cuda()
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.2).float().cuda()
+    w = (1 + torch.rand(H, W, generator=g)).cuda()
+    res = {}
+    for grad_ds, ms in ((2, 0), (1, 0), (2, 2)):
+        bufs = LossBuffers(B, Cc, H, W, ms, grad_ds, pred.device)
+        loss_prepare(bufs, B, Cc, H, W, mask, w, ms, grad_ds, 0.1)
+        d0, d1 = torch.empty_like(pred), torch.empty_like(pred)
+        out0 = torch.zeros(4, device="cuda"); out1 = torch.zeros(4, device="cuda")
+        args = (bufs, sx, B, Cc, H, W, pred, 8, target, mask, w, None, "huber", 0.05, 0.5, 0.1, "vector", "l1", ms, 0.5, grad_ds)
+        assert loss_forward_backward(*args, d0, 8, 0.5, out=out0) is False
+        slots = torch.full((L.SX_HEAD_BIAS_SLOTS * Cc,), 0.0, device="cuda")
+        loss_prepare(bufs, B, Cc, H, W, mask, w, ms, grad_ds, 0.1)
+        done = loss_forward_backward(*args, d1, 8, 0.5, out=out1, bias_sums=slots)
+        torch.cuda.synchronize()
+        # (the multi-scale denominators are fp32 atomics too: its two runs agree to the last bits only)
+        assert torch.equal(d0, d1) if ms == 0 else torch.allclose(d0.float(), d1.float(), rtol=1e-2 if sx else 1e-5, atol=1e-9)
+        assert torch.allclose(out0, out1, rtol=1e-5, atol=0)      # the numerators are fp32 atomics: equal up to order
+        res[(grad_ds, ms)] = done
+        if done:
+            got = slots.view(L.SX_HEAD_BIAS_SLOTS, Cc).sum(0)
+            ref = d1.float().sum((0, 1, 2))
+            assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+        else:
+            assert float(slots.abs().max()) == 0.0
+    assert res[(2, 0)] is True and res[(1, 0)] is False and res[(2, 2)] is False
+
+
 def test_normalizers_and_error_sums_match_golden(L, golden):
     from unet_amd import data as D
     from unet_amd.losses import batch_error_sums_ev, edge_weights
