@@ -418,68 +418,63 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
 struct WgReduceArgs { WgReduceDesc d[WG_MAX_REDUCE]; int n; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A) {
-  __shared__ f32x4 red[16][17];
+  // A WAVE owns a unit (256 contiguous bytes x all splits): lane = (split lane sl = lane / 16, e = lane % 16); a thread adds
+  // the float4 of splits sl, sl + 4, ... (independent loads, unrolled), the four split lanes are combined by two lane
+  // exchanges, lane (e, sl) stores element sl of the sum.  No LDS, no block barrier.  (Rounds 1-2: a BLOCK per unit, 16
+  // split lanes, one load per thread and two barriers per unit -- 6000 blocks of one unit each, 2.4 TB/s.)
   int di = 0;
   while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
   const WgReduceDesc& D = A.d[di];
   const int64_t slab_sz = (int64_t)D.ntaps * D.CaPad * D.CbPad;
-  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  if (D.tiled) {
-    // unit = four consecutive rows of one 16x16 tile (256 contiguous bytes) x all splits; thread e: row 4q + e/4, cols (e%4)*4..+3
-    const int A16 = D.CaPad >> 4, B16 = D.CbPad >> 4;
-    const int a16_n = D.a16_n ? D.a16_n : A16, tap_n = D.a16_n ? D.tap_n : D.ntaps;
-    const int64_t nunits = (int64_t)tap_n * a16_n * B16 * 4;
-    for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = lane & 15, sl = lane >> 4;
+  const int A16 = D.CaPad >> 4, B16 = D.CbPad >> 4;
+  const int a16_n = D.a16_n ? D.a16_n : A16, tap_n = D.a16_n ? D.tap_n : D.ntaps;
+  const int bchunks = (D.Cb + 63) >> 6;
+  const int64_t nunits = D.tiled ? (int64_t)tap_n * a16_n * B16 * 4 : (int64_t)D.ntaps * D.Ca * bchunks;
+  for (int64_t u = ((int64_t)((int)blockIdx.x - D.blk0)) * 4 + wave; u < nunits; u += (int64_t)D.nblk * 4) {
+    const float* src;
+    int aa, bb, tap, tn;
+    bool ok;
+    if (D.tiled) {
+      // unit = four consecutive rows of one 16x16 tile; thread e: row 4q + e/4, cols (e%4)*4..+3
       const int q = (int)(u & 3);
       const int64_t tl = u >> 2;                                // (tap * a16_n + a16) * B16 + b16, local to this descriptor
       const int b16 = (int)(tl % B16);
       const int64_t ta = tl / B16;
-      const int a16 = (int)(ta % a16_n), tap = (int)(ta / a16_n);
+      const int a16 = (int)(ta % a16_n);
+      tap = (int)(ta / a16_n);
       const int64_t tile = ((int64_t)(D.tap_lo + tap) * A16 + D.a16_lo + a16) * B16 + b16;
-      const float* src = D.slab + (tile << 8) + q * 64 + e * 4;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int k = sl; k < D.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
-      red[sl][e] = s;
-      __syncthreads();
-      if (sl < 4) {                      // thread (e, sl) finishes column (e%4)*4 + sl of row 4q + e/4
-        const int aa = a16 * 16 + q * 4 + (e >> 2), bb = b16 * 16 + (e & 3) * 4 + sl;
-        if (aa < D.Ca && bb < D.Cb) {
-          float t = 0.f;
-#pragma unroll
-          for (int l = 0; l < 16; ++l) t += red[l][e][sl];
-          float* dst = D.out + ((int64_t)aa * D.Cb + bb) * tap_n + tap;
-          *dst = D.accumulate ? (*dst + t) : t;
-        }
-      }
-      __syncthreads();
+      src = D.slab + (tile << 8) + q * 64 + e * 4;
+      aa = a16 * 16 + q * 4 + (e >> 2); bb = b16 * 16 + (e & 3) * 4 + sl; tn = tap_n;
+      ok = true;
+    } else {
+      // unit = 64 consecutive b of one (tap, a) row
+      const int bc = (int)(u % bchunks);
+      const int64_t row = u / bchunks;
+      aa = (int)(row % D.Ca); tap = (int)(row / D.Ca);
+      const int b = bc * 64 + e * 4;
+      src = D.slab + ((int64_t)tap * D.CaPad + aa) * D.CbPad + b;
+      bb = b + sl; tn = D.ntaps;
+      ok = b < D.CbPad;
     }
-    return;
-  }
-  const int bchunks = (D.Cb + 63) >> 6;
-  const int64_t nunits = (int64_t)D.ntaps * D.Ca * bchunks;
-  for (int64_t u = (int)blockIdx.x - D.blk0; u < nunits; u += D.nblk) {
-    const int bc = (int)(u % bchunks);
-    const int64_t row = u / bchunks;
-    const int aa = (int)(row % D.Ca), tap = (int)(row / D.Ca);
-    const int b = bc * 64 + e * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (b < D.CbPad) {
-      const float* src = D.slab + ((int64_t)tap * D.CaPad + aa) * D.CbPad + b;
-      for (int k = sl; k < D.nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
+    if (ok) {
+#pragma unroll 4
+      for (int k = sl; k < D.nsplit; k += 4) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
     }
-    red[sl][e] = s;
-    __syncthreads();
-    if (sl < 4) {                        // thread (e, sl) finishes column b + sl
-      const int bb = b + sl;
-      if (bb < D.Cb) {
-        float t = 0.f;
 #pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l][e][sl];
-        float* dst = D.out + ((int64_t)aa * D.Cb + bb) * D.ntaps + tap;
-        *dst = D.accumulate ? (*dst + t) : t;
-      }
+    for (int r = 0; r < 4; ++r) {
+      float v = s[r];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      s[r] = v;
     }
-    __syncthreads();
+    if (aa < D.Ca && bb < D.Cb) {
+      const float t = sl == 0 ? s[0] : (sl == 1 ? s[1] : (sl == 2 ? s[2] : s[3]));
+      float* dst = D.out + ((int64_t)aa * D.Cb + bb) * tn + tap;
+      *dst = D.accumulate ? (*dst + t) : t;
+    }
   }
 }
 
@@ -494,7 +489,7 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
                                                (A.d[i].a16_n ? A.d[i].a16_n : (A.d[i].CaPad >> 4)) * (A.d[i].CbPad >> 4) * 4
                                          : (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
       A.d[i].blk0 = blk;
-      A.d[i].nblk = (int)std::min<int64_t>(units, 1024);
+      A.d[i].nblk = (int)std::min<int64_t>((units + 3) / 4, 1024);      // four units (waves) per block
       blk += A.d[i].nblk;
     }
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blk), dim3(256), 0, st, A);
