@@ -305,8 +305,9 @@ __device__ __forceinline__ void store8_split(bf16* p, const f32x8& r, int planes
 
 template <typename T, int NT>
 __device__ __forceinline__ void pack_pair_tile(const PackPair& D, int co0, int ci0, float (*tile)[32 * 9 + 1], int split) {
-  constexpr int RUN = 32 * NT, TOTAL = 32 * RUN, U = 4;
-  // U independent loads in flight per thread (a block is 36 trips of one load otherwise, on ~1 block per CU)
+  constexpr int RUN = 32 * NT, TOTAL = 32 * RUN, U = NT == 9 ? 36 : 4;
+  // U independent loads in flight per thread (a block is 36 trips of one load otherwise, on ~1 block per CU): all 36 of a
+  // 3x3 tile at once (17.2 us per step with U = 4, 14.5 with 12, 13.3 with 36)
   for (int e0 = threadIdx.x; e0 < TOTAL; e0 += 256 * U) {
     float v[U];
 #pragma unroll
