@@ -275,7 +275,9 @@ int sx_gather_rows(const float* src, int64_t src_stride, int64_t n_src, const in
  *   sx_loss_prepare: mask (B,1,H,W) fp32, w (H,W) fp32 or NULL -> den[9] = per scale
  *                    {sum m, sum m*w, sum m_grad}; builds pooled masks in `workspace`.
  *   sx_loss_forward_backward: pred NHWC `dtype` (ld), target planar fp32 (B,C,H,W);
- *                    out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = sum mask
+ *                    out[0] = loss, out[1] = sum|pred-target|*mask, out[2] = sum mask (= den[0]: global if the
+ *                    caller all-reduced den between the two phases), out[3] = sum mask as sx_loss_prepare formed it on
+ *                    THIS rank (single scale; with multiscale > 0 out[3] = out[2])
  *                    (mae_norm, losses.py:226-227, is out[1]/max(out[2],1e-8));
  *                    d_pred (NHWC dtype, ld, channels >= C zeroed) = grad_scale * dloss/dpred, or NULL.
  * --------------------------------------------------------------------------------------------- */

@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256) void den_reduce_kernel(const float* __restrict
   for (int i = threadIdx.x; i < n; i += blockDim.x) { v[0] += part[i * 4]; v[1] += part[i * 4 + 1]; v[2] += part[i * 4 + 2]; }
   __shared__ float red[12];
   block_sum<3>(v, red);
-  if (threadIdx.x == 0) { den[0] = v[0]; den[1] = v[1]; den[2] = v[2]; }
+  if (threadIdx.x == 0) {
+    den[0] = v[0]; den[1] = v[1]; den[2] = v[2];
+    // this rank's own pixel count, kept where no all-reduce of `den` reaches it (the unused fourth float of partial 0):
+    // phase 2 reports it as out[3], so a data-parallel caller need not copy den[0] aside first
+    const_cast<float*>(part)[3] = v[0];
+  }
   if (threadIdx.x >= 3 && threadIdx.x < 9) den[threadIdx.x] = 0.f;
 }
 
@@ -442,6 +447,7 @@ struct FinalArgs {
   const float* den; float* num; const float* cw; int C;
   int nscales; float lam_w, lam_grad, ms_weight; int has_w;
   float* out;   // out[0] = loss, out[1] = sum|p-t|*m (scale 0), out[2] = out[3] = sum m (scale 0)
+  const float* local_px;   // nullable: out[3] = *local_px (sum m as phase 1 formed it here, before any all-reduce of den)
 };
 // One block: total the numerator slots (fixed order), write out[0..3], and leave the slots ZERO for the next call (the
 // single-scale path has no memset launch: sx_loss_prepare's reduction kernel zeroes them the first time).
@@ -467,7 +473,7 @@ __device__ __forceinline__ void loss_final_block(const FinalArgs& a) {
   a.out[0] = loss;
   a.out[1] = tot[2];
   a.out[2] = a.den[0];
-  a.out[3] = a.den[0];   // a DP caller overwrites this with its local pixel count (den is all-reduced by then)
+  a.out[3] = a.local_px ? *a.local_px : a.den[0];   // single scale: the local count; else a DP caller overwrites it
 }
 __global__ void loss_final_kernel(FinalArgs a) {
   if (blockIdx.x == 0) loss_final_block(a);
@@ -735,7 +741,7 @@ extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int
                       ((uintptr_t)pred % 16) == 0 && (!want_grad || ((uintptr_t)d_pred % 16) == 0);
     FinalArgs f;
     f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = 1; f.lam_w = lam_w; f.lam_grad = lam_grad;
-    f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
+    f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out; f.local_px = ws + L.PART + 3;
 #define SX_FUSE_LAUNCH(KERN, ...)                                                                               \
     do {                                                                                                        \
       if (dtype == SX_BF16) { if (fast) hipLaunchKernelGGL((KERN<bf16, true>), dim3(gsz(FUSE_CG * nwin)), dim3(256), 0, st, __VA_ARGS__);   \
@@ -824,7 +830,7 @@ extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int
   }
   FinalArgs f;
   f.den = den; f.num = num; f.cw = cw; f.C = C; f.nscales = L.ns; f.lam_w = lam_w; f.lam_grad = lam_grad;
-  f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out;
+  f.ms_weight = ms_weight; f.has_w = w != nullptr; f.out = out; f.local_px = L.ns == 1 ? ws + L.PART + 3 : nullptr;
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
   SX_LAUNCH_CHECK("loss_forward_backward");
   return SX_OK;

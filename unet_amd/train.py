@@ -180,7 +180,9 @@ class TrainEngine:
         loss_prepare(bufs, B, Cc, H, W, m, self.w_map, o["multiscale"], o["grad_ds"], float(lam_grad))
         px_local, handle = None, None
         if self.dp:
-            px_local = bufs.den[0].clone()
+            # (single scale: phase 1 keeps this rank's own pixel count in the loss workspace and phase 2 reports it as out[3];
+            # the multi-scale path has no such slot: copy den[0] aside before the all-reduce)
+            px_local = bufs.den[0].clone() if int(o["multiscale"]) != 0 else None
             handle = sxdist.all_reduce_sum(bufs.den, async_op=True)        # batch-global denominators
         return m, px_local, handle
 
@@ -248,10 +250,10 @@ class TrainEngine:
         if closing:
             if self.dp:
                 h_enc = sxdist.all_reduce_sum(self.flat_g[(self.n_bot if h_bot is not None else self.n_dec):], async_op=True)
-                h_dec.wait()
-                if h_bot is not None:
-                    h_bot.wait()
+                # one communicator stream executes the collectives in issue order: the last bucket's completion implies the
+                # earlier ones' (one stream hand-over instead of three)
                 h_enc.wait()
+                del h_dec, h_bot
             self.optimizer_step(lr, n=self.n_kernel if (fp is not None or self._film_pending) else self.n_film)
             self._film_pending = False
         elif fp is not None:
