@@ -578,6 +578,225 @@ __global__ __launch_bounds__(256) void grad_out_kernel(FuseArgs a, FinalArgs fin
   }
 }
 
+// ---------------------------------------------------------------- the three fused kernels above as ONE tile kernel (training)
+// Fast configuration only (2 x 2 windows, C <= 8 in 8-wide NHWC rows, even H, W, gradient wanted).  A block owns a tile of
+// TGH x TGW pooling windows of one sample and four channels and never leaves the chip between the phases: the pooled planes
+// of the tile + a halo of 2 and the Sobel-term gradients of the tile + a halo of 1 live in LDS, the base-term gradient of
+// the thread's own windows in registers.  HBM sees pred, target, mask once (+ the halo windows, served by L2) and d_pred:
+// ~40 MB instead of the ~140 MB of base_pool + sobel_fwd + grad_out (planar gradient, pooled planes, ux / uy round trips).
+static constexpr int LT_GH = 16, LT_GW = 32;                // windows per tile
+static constexpr int LT_EH1 = LT_GH + 4, LT_EW1 = LT_GW + 4, LT_P1 = LT_EW1 + 1;   // pooled planes: halo 2 (pitch padded)
+static constexpr int LT_EH2 = LT_GH + 2, LT_EW2 = LT_GW + 2, LT_P2 = LT_EW2 + 1;   // ux / uy: halo 1
+struct TileArgs {
+  FuseArgs f;
+  const float* mg;          // pooled + thresholded mask [B][gh][gw] (sx_loss_prepare)
+  int magnitude, gkind;     // gradient term: compare magnitudes / components; its pixel loss kind
+  float cgl;                // lam_grad
+  int tiles_x, tiles_y;
+};
+
+// Block = LT_NT threads for LT_GH x LT_GW windows x 4 channels: a thread owns ONE window x 2 channels (the first version,
+// 256 threads with two windows x 4 channels each, took 37 us: ~3000 VALU instructions per thread on two waves per SIMD).
+static constexpr int LT_NT = 1024;    // (8 x 32 tiles on 512 threads: 25.4 against 24.0 us)
+template <typename T>
+__global__ __launch_bounds__(LT_NT) void loss_tile_kernel(TileArgs A) {
+  constexpr int MC = 4, TC = 2;                 // channels per block / per thread
+  constexpr int NWIN = LT_GH * LT_GW;
+  static_assert(NWIN * (MC / TC) == LT_NT, "one (window, channel pair) per thread");
+  __shared__ float sP[MC][LT_EH1][LT_P1], sT[MC][LT_EH1][LT_P1];
+  __shared__ float sUX[MC][LT_EH2][LT_P2], sUY[MC][LT_EH2][LT_P2];
+  const FuseArgs& a = A.f;
+  const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * MC;
+  const int ty0 = (tile / A.tiles_x) * LT_GH, tx0 = (tile % A.tiles_x) * LT_GW;
+  const int gh = a.H >> 1, gw = a.W >> 1, hw = a.H * a.W;
+  const float scw = cw_sum(a.cw, a.C);
+  const float cb = 1.0f / fmaxf(a.den[0] * scw, 1e-8f);
+  const float ce = (a.w && a.lam_w != 0.f) ? a.lam_w / fmaxf(a.den[1] * scw, 1e-8f) : 0.f;
+  const float cg = A.cgl / fmaxf(a.den[2] * scw, 1e-8f);
+  const T* pred = reinterpret_cast<const T*>(a.pred);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- phase 1a: this thread's own window, two channels: base + edge terms, the base gradient (registers), pooled values
+  const int o = threadIdx.x % NWIN, cs = (threadIdx.x / NWIN) * TC;      // window inside the tile, first channel inside the block
+  const int oy = o / LT_GW, ox = o - oy * LT_GW;
+  const int wy = ty0 + oy, wx = tx0 + ox;
+  const bool own_in = wy < gh && wx < gw;
+  float cwv[TC];
+#pragma unroll
+  for (int c = 0; c < TC; ++c) cwv[c] = (c0 + cs + c < a.C) ? (a.cw ? a.cw[c0 + cs + c] : 1.f) : 0.f;
+  f32x2_ go[2][TC];
+  {
+    float sp[TC] = {0.f, 0.f}, st[TC] = {0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) go[dy][c] = f32x2_{0.f, 0.f};
+    if (own_in && c0 + cs < a.C) {
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int px = (wy * 2 + dy) * a.W + wx * 2;
+        const f32x2_ mm = *reinterpret_cast<const f32x2_*>(a.m + (int64_t)b * hw + px);
+        f32x2_ ww = {0.f, 0.f};
+        if (a.w) ww = *reinterpret_cast<const f32x2_*>(a.w + px);
+        const T* pp = pred + ((int64_t)b * hw + px) * 8 + c0 + cs;
+        const f32x2_ q0 = load2(pp), q1 = load2(pp + 8);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+          if (c0 + cs + c < a.C) {
+            const f32x2_ tt = *reinterpret_cast<const f32x2_*>(a.t + ((int64_t)b * a.C + c0 + cs + c) * hw + px);
+            const float pr[2] = {q0[c], q1[c]};
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const float d = pr[dx] - tt[dx];
+              const float l = px_val(a.kind, d, a.beta);
+              v[0] += l * mm[dx] * cwv[c];
+              v[1] += l * mm[dx] * ww[dx] * cwv[c];
+              v[2] += fabsf(d) * mm[dx];
+              go[dy][c][dx] = px_grad(a.kind, d, a.beta) * mm[dx] * cwv[c] * (cb + ce * ww[dx]);
+              sp[c] += pr[dx];
+              st[c] += tt[dx];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < TC; ++c) { sP[cs + c][oy + 2][ox + 2] = sp[c] * 0.25f; sT[cs + c][oy + 2][ox + 2] = st[c] * 0.25f; }
+  }
+  // ---- phase 1b: the halo ring of 2 windows: pooled values only (zero outside the image = the Sobel's zero padding)
+  {
+    constexpr int NRING = LT_EH1 * LT_EW1 - NWIN;      // 208 ring windows x 2 channel pairs <= LT_NT: one trip
+    static_assert(NRING * (MC / TC) <= LT_NT, "halo ring in one trip");
+    const int hI = threadIdx.x % NRING, hcs = (threadIdx.x / NRING) * TC;
+    if (threadIdx.x < NRING * (MC / TC)) {
+      // ring index -> (ey, ex): two full rows on top, two at the bottom, then 2 + 2 columns of the LT_GH middle rows
+      int ey, ex;
+      if (hI < 2 * LT_EW1) { ey = hI / LT_EW1; ex = hI - ey * LT_EW1; }
+      else if (hI < 4 * LT_EW1) { const int q = hI - 2 * LT_EW1; ey = LT_EH1 - 2 + q / LT_EW1; ex = q % LT_EW1; }
+      else { const int q = hI - 4 * LT_EW1; ey = 2 + (q >> 2); const int k4 = q & 3; ex = k4 < 2 ? k4 : LT_EW1 - 4 + k4; }
+      const int y = ty0 - 2 + ey, x = tx0 - 2 + ex;
+      float sp[TC] = {0.f, 0.f}, st[TC] = {0.f, 0.f};
+      if (y >= 0 && y < gh && x >= 0 && x < gw && c0 + hcs < a.C) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int px = (y * 2 + dy) * a.W + x * 2;
+          const T* pp = pred + ((int64_t)b * hw + px) * 8 + c0 + hcs;
+          const f32x2_ q0 = load2(pp), q1 = load2(pp + 8);
+#pragma unroll
+          for (int c = 0; c < TC; ++c)
+            if (c0 + hcs + c < a.C) {
+              const f32x2_ tt = *reinterpret_cast<const f32x2_*>(a.t + ((int64_t)b * a.C + c0 + hcs + c) * hw + px);
+              sp[c] += q0[c] + q1[c];
+              st[c] += tt[0] + tt[1];
+            }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < TC; ++c) { sP[hcs + c][ey][ex] = sp[c] * 0.25f; sT[hcs + c][ey][ex] = st[c] * 0.25f; }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: Sobel term on the tile + a ring of 1: its value (own windows only) and gradient w.r.t. (pgx, pgy)
+  for (int e = threadIdx.x; e < LT_EH2 * LT_EW2 * MC; e += LT_NT) {
+    const int c = e / (LT_EH2 * LT_EW2), pos = e - c * (LT_EH2 * LT_EW2);
+    const int ey = pos / LT_EW2, ex = pos - ey * LT_EW2;
+    const int y = ty0 - 1 + ey, x = tx0 - 1 + ex;
+    float ux = 0.f, uy = 0.f;
+    if (y >= 0 && y < gh && x >= 0 && x < gw && c0 + c < a.C) {
+      const bool own = ey >= 1 && ey <= LT_GH && ex >= 1 && ex <= LT_GW;
+      const float mm = A.mg[((int64_t)b * gh + y) * gw + x];
+      const float cwc = a.cw ? a.cw[c0 + c] : 1.f;
+      const float (*P)[LT_P1] = sP[c];
+      const float (*Q)[LT_P1] = sT[c];
+      const int r = ey + 1, q = ex + 1;          // centre in halo-2 coordinates
+      const float pgx = (P[r - 1][q + 1] - P[r - 1][q - 1]) + 2.f * (P[r][q + 1] - P[r][q - 1]) + (P[r + 1][q + 1] - P[r + 1][q - 1]);
+      const float pgy = (P[r + 1][q - 1] - P[r - 1][q - 1]) + 2.f * (P[r + 1][q] - P[r - 1][q]) + (P[r + 1][q + 1] - P[r - 1][q + 1]);
+      const float tgx = (Q[r - 1][q + 1] - Q[r - 1][q - 1]) + 2.f * (Q[r][q + 1] - Q[r][q - 1]) + (Q[r + 1][q + 1] - Q[r + 1][q - 1]);
+      const float tgy = (Q[r + 1][q - 1] - Q[r - 1][q - 1]) + 2.f * (Q[r + 1][q] - Q[r - 1][q]) + (Q[r + 1][q + 1] - Q[r - 1][q + 1]);
+      float l, dgx, dgy;
+      if (A.magnitude) {
+        const float Pm = sqrtf(pgx * pgx + pgy * pgy + 1e-12f), Tm = sqrtf(tgx * tgx + tgy * tgy + 1e-12f);
+        l = px_val(A.gkind, Pm - Tm, a.beta);
+        const float gr = px_grad(A.gkind, Pm - Tm, a.beta);
+        dgx = gr * pgx / Pm;
+        dgy = gr * pgy / Pm;
+      } else {
+        const float dx = pgx - tgx, dy = pgy - tgy;
+        l = px_val(A.gkind, dx, a.beta) + px_val(A.gkind, dy, a.beta);
+        dgx = px_grad(A.gkind, dx, a.beta);
+        dgy = px_grad(A.gkind, dy, a.beta);
+      }
+      if (own) v[3] += l * mm * cwc;
+      const float sc = mm * cwc * cg;
+      ux = dgx * sc;
+      uy = dgy * sc;
+    }
+    sUX[c][ey][ex] = ux;
+    sUY[c][ey][ex] = uy;
+  }
+  __syncthreads();
+  // ---- phase 3: transposed Sobel of the own window + the base gradient -> d_pred (NHWC), head bias sums
+  T* out = reinterpret_cast<T*>(a.dpred);
+  float bsum[TC] = {0.f, 0.f};
+  if (own_in) {
+    float d[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      const float (*X)[LT_P2] = sUX[cs + c];
+      const float (*Y)[LT_P2] = sUY[cs + c];
+      const int r = oy + 1, q = ox + 1;
+      float t = 0.f;
+      t += -1.f * X[r + 1][q + 1] + 1.f * X[r + 1][q - 1];
+      t += -2.f * X[r][q + 1] + 2.f * X[r][q - 1];
+      t += -1.f * X[r - 1][q + 1] + 1.f * X[r - 1][q - 1];
+      t += -1.f * Y[r + 1][q + 1] - 2.f * Y[r + 1][q] - 1.f * Y[r + 1][q - 1];
+      t += 1.f * Y[r - 1][q + 1] + 2.f * Y[r - 1][q] + 1.f * Y[r - 1][q - 1];
+      d[c] = t * 0.25f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int px = (wy * 2 + dy) * a.W + wx * 2;
+      f32x2_ o0, o1;
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        o0[c] = c0 + cs + c < a.C ? a.scale * (d[c] + go[dy][c][0]) : 0.f;
+        o1[c] = c0 + cs + c < a.C ? a.scale * (d[c] + go[dy][c][1]) : 0.f;
+      }
+      T* dst = out + ((int64_t)b * hw + px) * 8 + c0 + cs;
+      store2(dst, o0);
+      store2(dst + 8, o1);
+#pragma unroll
+      for (int c = 0; c < TC; ++c) bsum[c] += (float)(T)o0[c] + (float)(T)o1[c];
+    }
+  }
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  __shared__ float red[4 * (LT_NT / 64)];
+  block_sum<4>(v, red);
+  if (threadIdx.x == 0 && c0 < a.C) {
+    float* num = a.num + (lin & (NSLOT - 1)) * SLOT_STRIDE;
+    atomicAdd(num + 0, v[0]);
+    atomicAdd(num + 1, v[1]);
+    atomicAdd(num + 2, v[2]);
+    atomicAdd(num + 3, v[3]);
+  }
+  if (a.bias_sums && c0 < a.C) {
+    // waves 0..7 hold channel pair 0, waves 8..15 pair 1 (NWIN = 512 threads each)
+    __shared__ float bred[LT_NT / 64][TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      float t = bsum[c];
+      for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+      if ((threadIdx.x & 63) == 0) bred[threadIdx.x >> 6][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < MC && c0 + (int)threadIdx.x < a.C) {
+      const int pair = threadIdx.x / TC, c = threadIdx.x % TC;
+      float t = 0.f;
+      for (int w = 0; w < NWIN / 64; ++w) t += bred[pair * (NWIN / 64) + w][c];
+      atomicAdd(a.bias_sums + (lin % SX_HEAD_BIAS_SLOTS) * a.C + c0 + threadIdx.x, t);
+    }
+  }
+}
+
 // fine[p] += coarse[q(p)] / 4   (avg_pool2d(2) backward), floor semantics: trailing odd row/col untouched
 __global__ void unpool2_add_kernel(const float* __restrict__ coarse, float* __restrict__ fine, int64_t planes, int h, int w, int hf, int wf) {
   const int64_t n = planes * h * w;
@@ -749,6 +968,23 @@ extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int
       else { if (fast) hipLaunchKernelGGL((KERN<float, true>), dim3(gsz(FUSE_CG * nwin)), dim3(256), 0, st, __VA_ARGS__);                   \
              else hipLaunchKernelGGL((KERN<float, false>), dim3(gsz(nwin)), dim3(256), 0, st, __VA_ARGS__); }                     \
     } while (0)
+    static const int tile_on = env_int("SX_LOSS_TILE", 1);      // A/B knob: 0 = the three-kernel form
+    if (tile_on && fast && want_grad) {
+      TileArgs ta;
+      ta.f = fa; ta.f.g = nullptr;
+      ta.mg = ws + L.MG[0]; ta.magnitude = grad_magnitude; ta.gkind = grad_kind; ta.cgl = lam_grad;
+      ta.tiles_x = cdiv(gw, LT_GW); ta.tiles_y = cdiv(gh, LT_GH);
+      if (bias_sums) {
+        ta.f.bias_sums = bias_sums;
+        if (bias_done) *bias_done = 1;
+      }
+      const dim3 grid(ta.tiles_x * ta.tiles_y, B, 2);
+      if (dtype == SX_BF16) hipLaunchKernelGGL(loss_tile_kernel<bf16>, grid, dim3(LT_NT), 0, st, ta);
+      else hipLaunchKernelGGL(loss_tile_kernel<float>, grid, dim3(LT_NT), 0, st, ta);
+      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+      SX_LAUNCH_CHECK("loss_forward_backward");
+      return SX_OK;
+    }
     SX_FUSE_LAUNCH(base_pool_kernel, fa);
     SobelArgs sa;
     sa.p = ws + L.PG[0]; sa.t = ws + L.TG[0]; sa.m = ws + L.MG[0]; sa.cw = cw;
