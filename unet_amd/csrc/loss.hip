@@ -182,6 +182,14 @@ struct BaseArgs {
 __device__ __forceinline__ float cw_sum(const float* cw, int C) {
   if (!cw) return (float)C;
   float s = 0.f;
+  if (C <= 16) {            // independent guarded loads, one memory latency (a loop of dependent trips pays one per channel)
+    float t[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[c] = c < C ? cw[c] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += t[c];
+    return s;
+  }
   for (int c = 0; c < C; ++c) s += cw[c];
   return s;
 }
