@@ -80,6 +80,8 @@ for pos, name in step:
         byt, what = B * 128 * 64 * (8 * 2 + 8 * 4 + 4 + 8 * 4) + 4 * B * 64 * 32 * 8 * 4, "loss: base+edge terms, planar gradient, pooled fields"
     elif k == "grad_out":
         byt, what = B * 128 * 64 * (8 * 4 + 8 * 2) + 2 * B * 64 * 32 * 8 * 4, "loss: transposed Sobel + NHWC gradient write"
+    elif k == "loss_tile":
+        byt, what = B * 128 * 64 * (8 * 2 + 8 * 4 + 4 + 8 * 2) + 4 * B * 64 * 32, "loss, one tile kernel: read pred, target, mask, pooled mask; write d(pred)"
     elif k == "sobel_fwd":
         byt, what = 6 * B * 64 * 32 * 8 * 4, "loss: Sobel of pooled pred/target + its gradient"
     elif k == "wgrad_reduce_multi":
