@@ -653,6 +653,48 @@ def test_loss_forms_the_head_bias_gradient_on_the_way_out(L, tdtype):
     assert res[(2, 0)] is True and res[(1, 0)] is False and res[(2, 2)] is False
 
 
+@pytest.mark.parametrize("tdtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("Cc,H,W,gmode,gbase", [(8, 72, 136, "vector", "l1"), (5, 72, 136, "magnitude", "huber"),
+                                               (8, 32, 16, "vector", "mse"), (3, 34, 66, "vector", "l1")])
+def test_loss_tile_kernel_against_the_oracle_across_tile_borders(L, tdtype, Cc, H, W, gmode, gbase):
+    """The one-kernel training loss (16 x 32 pooling windows per tile): grids of several tiles in both directions with partial
+    tiles at the borders, channel counts that leave one channel group partly or wholly empty; value and d_pred against the
+    oracle's autograd on the same (rounded) prediction."""
+    from unet_amd.losses import LossBuffers, loss_prepare, loss_forward_backward
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(H + W + Cc)
+    B = 3
+    sx = 1 if tdtype == torch.bfloat16 else 0
+    pred = torch.zeros(B, H, W, 8)
+    pred[..., :Cc] = torch.randn(B, H, W, Cc, generator=g)
+    pred = pred.to(tdtype)
+    target = torch.randn(B, Cc, H, W, generator=g)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.25).float()
+    w = 1 + torch.rand(H, W, generator=g)
+    cw = 0.5 + torch.rand(Cc, generator=g)
+    pr = pred.float()[..., :Cc].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = loss_ref.masked_weighted_loss(pr, target, mask, w=w, lam_grad=0.1, lam_w=0.5, base="huber", huber_beta=0.05,
+                                        grad_mode=gmode, grad_base=gbase, multiscale=0, grad_ds=2, channel_weights=cw)
+    ref.backward()
+    bufs = LossBuffers(B, Cc, H, W, 0, 2, "cuda")
+    md, wd, cwd, pd, td = mask.cuda(), w.cuda(), cw.cuda(), pred.cuda(), target.cuda()
+    loss_prepare(bufs, B, Cc, H, W, md, wd, 0, 2, 0.1)
+    d = torch.full_like(pd, 7.0)
+    out = torch.zeros(4, device="cuda")
+    slots = torch.zeros(L.SX_HEAD_BIAS_SLOTS * Cc, device="cuda")
+    done = loss_forward_backward(bufs, sx, B, Cc, H, W, pd, 8, td, md, wd, cwd, "huber", 0.05, 0.5, 0.1, gmode, gbase, 0, 0.5, 2,
+                                 d, 8, 1.0, out=out, bias_sums=slots)
+    torch.cuda.synchronize()
+    assert done
+    assert abs(float(out[0]) - float(ref)) < 1e-5 * abs(float(ref))
+    got = d.float().cpu()
+    assert float(got[..., Cc:].abs().max()) == 0.0 if Cc < 8 else True
+    gref = pr.grad.permute(0, 2, 3, 1)
+    tol = 1e-2 if sx else 1e-5
+    assert rel_err(got[..., :Cc], gref) < tol
+    assert rel_err(slots.view(L.SX_HEAD_BIAS_SLOTS, Cc).sum(0).cpu(), got[..., :Cc].sum((0, 1, 2))) < 1e-5
+
+
 def test_normalizers_and_error_sums_match_golden(L, golden):
     from unet_amd import data as D
     from unet_amd.losses import batch_error_sums_ev, edge_weights
