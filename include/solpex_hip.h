@@ -417,6 +417,12 @@ int     sx_unet_pack_weights(const sx_unet_desc* d, const float* const* params, 
 int     sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
                        const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
                        const float* film_params, void* stream);
+/* sx_unet_pack_weights followed by sx_unet_encode in one call (a training step repacks every step: train.py:221-233 change the
+ * weights).  The weight packs, the input pack and every FiLM generator run as block ranges of ONE launch where their tables
+ * fit the kernel-argument segment (<= 24 paired 3x3 / 1x1 weights, <= 8 others, <= 8 generators); otherwise as the two calls. */
+int     sx_unet_pack_encode(const sx_unet_desc* d, const float* const* params, void* wpack, void* ws,
+                            const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                            const float* film_params, void* stream);
 /* drop: HOST array of `depth` device pointers to fp32 [B][C] dropout factors (entries or the array may be NULL) */
 int     sx_unet_decode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
                        const float* film_params, const float* const* drop, void* stream);

@@ -146,6 +146,12 @@ class UNetSession:
         L.check(self.lib.sx_unet_encode(C.byref(self.desc), self._ptable, L.ptr(self.wpack), L.ptr(self.ws), L.ptr(x),
                                         sb, sc, sh, sw, L.ptr(film_params), L.stream_ptr()), "sx_unet_encode")
 
+    def pack_encode(self, x, film_params):
+        """pack_weights() + encode() in one call: one launch for the weight packs, the input pack and the FiLM generators."""
+        sb, sc, sh, sw = x.stride()
+        L.check(self.lib.sx_unet_pack_encode(C.byref(self.desc), self._ptable, L.ptr(self.wpack), L.ptr(self.ws), L.ptr(x),
+                                             sb, sc, sh, sw, L.ptr(film_params), L.stream_ptr()), "sx_unet_pack_encode")
+
     def decode(self, film_params, drop_table=None):
         L.check(self.lib.sx_unet_decode(C.byref(self.desc), self._ptable, L.ptr(self.wpack), L.ptr(self.ws),
                                         L.ptr(film_params), drop_table, L.stream_ptr()), "sx_unet_decode")

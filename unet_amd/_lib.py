@@ -96,6 +96,7 @@ SIGNATURES = {
     "sx_unet_view": (_i, [_D, _i, _i, C.POINTER(View)]),
     "sx_unet_pack_weights": (_i, [_D, _pp, _p, _p]),
     "sx_unet_encode": (_i, [_D, _pp, _p, _p, _p, _l, _l, _l, _l, _p, _p]),
+    "sx_unet_pack_encode": (_i, [_D, _pp, _p, _p, _p, _l, _l, _l, _l, _p, _p]),
     "sx_unet_decode": (_i, [_D, _pp, _p, _p, _p, _pp, _p]),
     "sx_unet_decode_backward": (_i, [_D, _pp, _pp, _p, _p, _p, _pp, _i, _p]),
     "sx_unet_encode_backward": (_i, [_D, _pp, _pp, _p, _p, _p, _i, _p]),

@@ -150,5 +150,14 @@ struct PackPad { const float* src; float* dst; int n, npad; };
 struct PackArgs { PackDesc d[PACK_MAX]; int n; PackPad pad; int split; };
 int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int Cout, int Cin, void* packed, PackDesc* d);
 int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad = nullptr);
+// The weight packs, the input pack and the FiLM generators of a training step's forward pass as block ranges of ONE launch
+// (conv_igemm.hip: encode_head_kernel).  0 = launched, 1 = tables too large for the kernel-argument segment (run them separately).
+struct FilmArgs;
+struct EncodeHeadExtra {
+  const FilmArgs& film;                                        // forward fields only (ngen may be 0)
+  const float* x; int64_t sb, sc, sh, sw; void* xout;          // input pack
+  int B, Cx, H, W, xld;
+};
+int encode_head_launch(int dtype, const PackDesc* descs, int n, const PackPad* pad, const EncodeHeadExtra& E, hipStream_t st);
 
 }  // namespace sx

@@ -17,6 +17,7 @@
 // wave runs ntaps x MI x NI MFMAs on fragments read straight from those two images.
 #include "conv_common.h"
 #include "norm_act.h"
+#include "film.h"
 #include <vector>
 #include <stdlib.h>
 
@@ -236,17 +237,14 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ weight packing
 // out[tap][row][k] for every layer of a descriptor table (one launch packs the whole network)
+// one block (index `blk` inside the descriptor's D.nblk blocks) of the element-per-thread pack
 template <typename T>
-__global__ void pack_weight_kernel(PackArgs A) {
-  if (blockIdx.x == 0 && A.pad.dst && (int)threadIdx.x < A.pad.npad)
-    A.pad.dst[threadIdx.x] = (int)threadIdx.x < A.pad.n ? A.pad.src[threadIdx.x] : 0.f;
-  int di = 0;
-  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
-  const PackDesc& D = A.d[di];
+__device__ __forceinline__ void pack_weight_block(const PackDesc& D, int blk, int split_planes) {
+  struct { int split; } A = {split_planes};
   const float* __restrict__ w = D.w;
   T* __restrict__ out = reinterpret_cast<T*>(D.out);
   const int mode = D.mode, tflip = D.tflip, Cout = D.Cout, Cin = D.Cin, RTot = D.RTot, RPad = D.RPad, KPad = D.KPad;
-  for (int64_t idx = ((int)blockIdx.x - D.blk0) * (int64_t)blockDim.x + threadIdx.x; idx < D.total;
+  for (int64_t idx = blk * (int64_t)blockDim.x + threadIdx.x; idx < D.total;
        idx += (int64_t)D.nblk * blockDim.x) {
     const int k = (int)(idx % KPad);
     const int64_t t2 = idx / KPad;
@@ -277,6 +275,15 @@ __global__ void pack_weight_kernel(PackArgs A) {
       }
     } else out[idx] = from_f32<T>(v);
   }
+}
+
+template <typename T>
+__global__ void pack_weight_kernel(PackArgs A) {
+  if (blockIdx.x == 0 && A.pad.dst && (int)threadIdx.x < A.pad.npad)
+    A.pad.dst[threadIdx.x] = (int)threadIdx.x < A.pad.n ? A.pad.src[threadIdx.x] : 0.f;
+  int di = 0;
+  while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
+  pack_weight_block<T>(A.d[di], (int)blockIdx.x - A.d[di].blk0, A.split);
 }
 
 // Forward pack [tap][co][ci] and transposed + tap-flipped pack [nt-1-tap][ci][co] of one 3x3 / 1x1 weight from ONE read:
@@ -365,6 +372,82 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairArgs A) {
   else pack_pair_tile<T, 1>(D, co0, ci0, tile, A.split);
 }
 
+// ------------------------------------------------------------------ the head of a training step's forward pass in ONE launch
+// Weight packs (pair tiles + the element-per-thread rest + the head's bias pad), the input pack and every FiLM generator are
+// mutually independent and each too small to fill the chip (277 + 832 + 2048 + 448 blocks of 5-14 us): as four launches they
+// cost their sum, as block ranges of one grid about the longest of them.  Tables sized to stay inside the 4 KB kernel-argument
+// segment; networks that exceed them take the separate launches.
+static constexpr int HEAD_PAIRS = 24, HEAD_REST = 8, HEAD_GEN = 8;
+struct HeadFilm { const float* w1; const float* b1; const float* w2; const float* b2; float* gf; float* bf; float* pre; int C; };
+struct HeadArgs {
+  PackPair pair[HEAD_PAIRS];
+  PackDesc rest[HEAD_REST];
+  HeadFilm gen[HEAD_GEN];
+  PackPad pad;
+  const float* x; int64_t sb, sc, sh, sw; void* xout;          // input pack
+  const float* fparams; float* zero;                           // FiLM: [B][P] inputs; words the launch also clears
+  int n_pair, n_rest, ngen, split;
+  int B, Cx, H, W, xld, P, Hf, zero_n;
+  int blk_pair, blk_film, blk_rest, blk_in;                    // block counts of the four roles, in this order
+};
+static_assert(sizeof(HeadArgs) <= 4096, "kernel-argument segment");
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_head_kernel(HeadArgs A) {
+  __shared__ float tile[32][32 * 9 + 1];
+  int blk = blockIdx.x;
+  if (blk < A.blk_pair) {
+    int di = 0;
+    while (di + 1 < A.n_pair && blk >= A.pair[di + 1].blk0) ++di;
+    const PackPair& D = A.pair[di];
+    const int tb = blk - D.blk0;
+    const int co0 = (tb / D.tiles_ci) * 32, ci0 = (tb % D.tiles_ci) * 32;
+    if (D.nt == 9) pack_pair_tile<T, 9>(D, co0, ci0, tile, A.split);
+    else pack_pair_tile<T, 1>(D, co0, ci0, tile, A.split);
+    return;
+  }
+  blk -= A.blk_pair;
+  if (blk < A.blk_film) {
+    float* hid = &tile[0][0];                  // FILM_MAX_HID floats
+    float* pv = hid + FILM_MAX_HID;
+    if (A.zero) {
+      const int nthr = A.blk_film * blockDim.x;
+      for (int i = blk * blockDim.x + threadIdx.x; i < A.zero_n; i += nthr) A.zero[i] = 0.f;
+    }
+    const int gi = blk / A.B, b = blk - gi * A.B;
+    const HeadFilm& G = A.gen[gi];
+    film_fwd_block(G.w1, G.b1, G.w2, G.b2, G.gf, G.bf, G.pre, G.C, b, A.P, A.Hf, A.fparams, hid, pv);
+    return;
+  }
+  blk -= A.blk_film;
+  if (blk < A.blk_rest) {
+    if (blk == 0 && A.pad.dst && (int)threadIdx.x < A.pad.npad)
+      A.pad.dst[threadIdx.x] = (int)threadIdx.x < A.pad.n ? A.pad.src[threadIdx.x] : 0.f;
+    int di = 0;
+    while (di + 1 < A.n_rest && blk >= A.rest[di + 1].blk0) ++di;
+    pack_weight_block<T>(A.rest[di], blk - A.rest[di].blk0, A.split);
+    return;
+  }
+  blk -= A.blk_rest;
+  {   // input pack: (B, C, H, W) fp32 with element strides -> NHWC T, xld channels, zero padded (misc.hip: pack_input_kernel)
+    const int groups = A.xld >> 3;
+    const int64_t total = (int64_t)A.B * A.H * A.W * groups;
+    T* out = reinterpret_cast<T*>(A.xout);
+    for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)A.blk_in * blockDim.x) {
+      const int c0 = (int)(i % groups) << 3;
+      int64_t q = i / groups;
+      const int w = (int)(q % A.W); q /= A.W;
+      const int h = (int)(q % A.H);
+      const int b = (int)(q / A.H);
+      const float* src = A.x + b * A.sb + h * A.sh + w * A.sw;
+      f32x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v.v[e] = c0 + e < A.Cx ? src[(c0 + e) * A.sc] : 0.f;
+      store8(out + (i << 3), v);
+    }
+  }
+}
+
 struct PackGeom { int ntaps, R, K, RPad, RTot, KPad; };
 static PackGeom pack_geom(int mode, int dtype, int tflip, int Cout, int Cin) {
   const int CK = 32;       // both tiers pad K to 32 (fp32: the split form walks 32-channel chunks, the exact form 16)
@@ -411,10 +494,61 @@ int pack_desc_fill(int dtype, int mode, int transpose_flip, const float* w, int 
   return SX_OK;
 }
 
-int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad) {
-  // adjacent (forward, transposed) descriptors of the same 3x3 / 1x1 weight go through the tile kernel, one read for both
+static void pack_split_pairs(const PackDesc* descs, int n, std::vector<PackPair>& pairs, std::vector<PackDesc>& rest);
+
+// 0 = launched; 1 = the tables do not fit (the caller takes the separate launches)
+int encode_head_launch(int dtype, const PackDesc* descs, int n, const PackPad* pad, const EncodeHeadExtra& E, hipStream_t st) {
+  static const int on = env_int("SX_HEAD_MERGED", 1);        // A/B knob
   std::vector<PackDesc> rest;
   std::vector<PackPair> pairs;
+  pack_split_pairs(descs, n, pairs, rest);
+  if (!on || pairs.size() > (size_t)HEAD_PAIRS || rest.size() > (size_t)HEAD_REST || rest.empty() || E.film.ngen > HEAD_GEN ||
+      E.film.Hf > FILM_MAX_HID || E.film.P > 64 || E.xld % 8)
+    return 1;
+  for (int i = 0; i < E.film.ngen; ++i)
+    if (E.film.g[i].C > 1024) return 1;
+  HeadArgs A;
+  memset(&A, 0, sizeof(A));
+  A.split = dtype == SX_F32 ? fp32_planes() : 0;
+  A.n_pair = (int)pairs.size(); A.n_rest = (int)rest.size(); A.ngen = E.film.ngen;
+  int blk = 0;
+  for (int i = 0; i < A.n_pair; ++i) {
+    A.pair[i] = pairs[i];
+    const int tiles_co = cdiv(std::max(A.pair[i].RTot_f, A.pair[i].KPad_t), 32);
+    A.pair[i].tiles_ci = cdiv(std::max(A.pair[i].KPad_f, A.pair[i].RTot_t), 32);
+    A.pair[i].blk0 = blk;
+    blk += tiles_co * A.pair[i].tiles_ci;
+  }
+  A.blk_pair = blk;
+  A.B = E.B;
+  A.blk_film = E.film.ngen * E.B;
+  for (int i = 0; i < A.ngen; ++i) {
+    const FilmGenDesc& g = E.film.g[i];
+    A.gen[i].w1 = g.w1; A.gen[i].b1 = g.b1; A.gen[i].w2 = g.w2; A.gen[i].b2 = g.b2;
+    A.gen[i].gf = g.gf; A.gen[i].bf = g.bf; A.gen[i].pre = g.pre; A.gen[i].C = g.C;
+  }
+  A.P = E.film.P; A.Hf = E.film.Hf; A.fparams = E.film.params; A.zero = E.film.zero; A.zero_n = E.film.zero_n;
+  blk = 0;
+  for (int i = 0; i < A.n_rest; ++i) {
+    A.rest[i] = rest[i];
+    A.rest[i].blk0 = blk;
+    A.rest[i].nblk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(A.rest[i].total, 256), 256));
+    blk += A.rest[i].nblk;
+  }
+  A.blk_rest = blk;
+  if (pad) A.pad = *pad;
+  A.x = E.x; A.sb = E.sb; A.sc = E.sc; A.sh = E.sh; A.sw = E.sw; A.xout = E.xout;
+  A.Cx = E.Cx; A.H = E.H; A.W = E.W; A.xld = E.xld;
+  const int64_t items = (int64_t)E.B * E.H * E.W * (E.xld / 8);
+  A.blk_in = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256), 2048));
+  const int grid = A.blk_pair + A.blk_film + A.blk_rest + A.blk_in;
+  if (dtype == SX_BF16) hipLaunchKernelGGL(encode_head_kernel<bf16>, dim3(grid), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(encode_head_kernel<float>, dim3(grid), dim3(256), 0, st, A);
+  SX_LAUNCH_CHECK("encode_head");
+  return SX_OK;
+}
+
+static void pack_split_pairs(const PackDesc* descs, int n, std::vector<PackPair>& pairs, std::vector<PackDesc>& rest) {
   for (int i = 0; i < n; ++i) {
     const PackDesc& f = descs[i];
     if (i + 1 < n && (f.mode == SX_CONV3 || f.mode == SX_CONV1) && !f.tflip && descs[i + 1].tflip && descs[i + 1].w == f.w &&
@@ -430,6 +564,13 @@ int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, 
       rest.push_back(f);
     }
   }
+}
+
+int pack_weights_multi(int dtype, const PackDesc* descs, int n, hipStream_t st, const PackPad* pad) {
+  // adjacent (forward, transposed) descriptors of the same 3x3 / 1x1 weight go through the tile kernel, one read for both
+  std::vector<PackDesc> rest;
+  std::vector<PackPair> pairs;
+  pack_split_pairs(descs, n, pairs, rest);
   for (size_t i0 = 0; i0 < pairs.size(); i0 += PAIR_MAX) {
     PackPairArgs A;
     A.split = dtype == SX_F32 ? fp32_planes() : 0;

@@ -26,6 +26,28 @@ struct FilmArgs {
   float* zero; int zero_n;   // forward only: fp32 words the launch also clears (the network's GroupNorm statistics; saves a memset dispatch)
 };
 
+// One block of the forward pass: generator (w1, b1, w2, b2) for sample b.  hid: FILM_MAX_HID floats of LDS, pv: 64.
+// Shared by film_fwd_kernel and the merged encode-head launch (conv_igemm.hip).
+__device__ __forceinline__ void film_fwd_block(const float* w1, const float* b1, const float* w2, const float* b2, float* gf, float* bf,
+                                               float* pre, int C, int b, int P, int Hf, const float* params, float* hid, float* pv) {
+  for (int p = threadIdx.x; p < P; p += blockDim.x) pv[p] = params[(int64_t)b * P + p];
+  __syncthreads();
+  for (int j = threadIdx.x; j < Hf; j += blockDim.x) {
+    float s = b1[j];
+    for (int p = 0; p < P; ++p) s += w1[j * P + p] * pv[p];
+    if (pre) pre[(int64_t)b * Hf + j] = s;
+    hid[j] = siluf_(s);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) {
+    float s = b2[k];
+    const float* w = w2 + (int64_t)k * Hf;
+    for (int j = 0; j < Hf; ++j) s += w[j] * hid[j];
+    if (k < C) gf[(int64_t)b * C + k] = 1.0f + s;
+    else bf[(int64_t)b * C + (k - C)] = s;
+  }
+}
+
 int film_forward(const FilmArgs& a, hipStream_t st);
 // gn (nullable): GroupNorm affine / bias gradient reductions of the same backward half.  In a training step (weight gradients
 // wanted, no gradient w.r.t. the FiLM inputs) ONE launch runs the dW2 rows, the dW1 rows -- each block rebuilding the dpre

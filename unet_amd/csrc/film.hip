@@ -37,22 +37,7 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(const FilmArgs) {
     const int nthr = gridDim.x * gridDim.y * blockDim.x;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < a.zero_n; i += nthr) a.zero[i] = 0.f;
   }
-  for (int p = threadIdx.x; p < a.P; p += blockDim.x) pv[p] = a.params[(int64_t)b * a.P + p];
-  __syncthreads();
-  for (int j = threadIdx.x; j < a.Hf; j += blockDim.x) {
-    float s = d.b1[j];
-    for (int p = 0; p < a.P; ++p) s += d.w1[j * a.P + p] * pv[p];
-    if (d.pre) d.pre[(int64_t)b * a.Hf + j] = s;
-    hid[j] = siluf_(s);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < 2 * d.C; k += blockDim.x) {
-    float s = d.b2[k];
-    const float* w = d.w2 + (int64_t)k * a.Hf;
-    for (int j = 0; j < a.Hf; ++j) s += w[j] * hid[j];
-    if (k < d.C) d.gf[(int64_t)b * d.C + k] = 1.0f + s;
-    else d.bf[(int64_t)b * d.C + (k - d.C)] = s;
-  }
+  film_fwd_block(d.w1, d.b1, d.w2, d.b2, d.gf, d.bf, d.pre, d.C, b, a.P, a.Hf, a.params, hid, pv);
 }
 
 // phase A (grid = samples/8 x ngen): dpre[b][j] = (sum_k dout[b][k] W2[k][j]) * silu'(pre[b][j]);

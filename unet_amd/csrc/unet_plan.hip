@@ -498,13 +498,9 @@ extern "C" int sx_unet_view(const sx_unet_desc* d, int which, int index, sx_view
   return SX_OK;
 }
 
-extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* params, void* wpack, void* stream) {
-  Plan p;
-  SX_TRY(build_plan(d, p));
-  Fp32WideScope fp32_scope(plan_wide_mode(p));
-  SX_REQUIRE(params && wpack, "sx_unet_pack_weights: null pointer");
+// every packed weight of the network (forward / transposed pairs adjacent) + the head's zero-padded bias
+static int pack_list(const Plan& p, const sx_unet_desc* d, const float* const* params, void* wpack, std::vector<PackDesc>& pk, PackPad& pad) {
   const int dt = d->dtype;
-  std::vector<PackDesc> pk;
   auto add = [&](int mode, int tflip, const float* w, int Cout, int Cin, void* out) {
     PackDesc pd;
     SX_TRY(pack_desc_fill(dt, mode, tflip, w, Cout, Cin, out, &pd));
@@ -528,14 +524,26 @@ extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* p
   SX_TRY(add(SX_CONV1, 0, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headf)));
   SX_TRY(add(SX_CONV1, 1, params[p.out_pidx], d->out_ch, p.C[0], at(wpack, p.headd)));
   SX_REQUIRE(p.out_pad <= 64, "sx_unet_pack_weights: out_ch %d too large", d->out_ch);
-  PackPad pad;                                     // the head's bias, zero padded, rides on the packing launch
+  // the head's bias, zero padded, rides on the packing launch
   pad.src = params[p.out_pidx + 1]; pad.dst = (float*)at(wpack, p.head_bias); pad.n = d->out_ch; pad.npad = p.out_pad;
-  return pack_weights_multi(dt, pk.data(), (int)pk.size(), (hipStream_t)stream, &pad);
+  return SX_OK;
 }
 
-extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
-                              const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
-                              const float* film_params, void* stream) {
+extern "C" int sx_unet_pack_weights(const sx_unet_desc* d, const float* const* params, void* wpack, void* stream) {
+  Plan p;
+  SX_TRY(build_plan(d, p));
+  Fp32WideScope fp32_scope(plan_wide_mode(p));
+  SX_REQUIRE(params && wpack, "sx_unet_pack_weights: null pointer");
+  std::vector<PackDesc> pk;
+  PackPad pad;
+  SX_TRY(pack_list(p, d, params, wpack, pk, pad));
+  return pack_weights_multi(d->dtype, pk.data(), (int)pk.size(), (hipStream_t)stream, &pad);
+}
+
+// pack != 0: sx_unet_pack_weights first -- and, where the tables fit, in ONE launch with the input pack and the FiLM generators
+static int encode_impl(const sx_unet_desc* d, const float* const* params, void* wpack, void* ws,
+                       const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                       const float* film_params, void* stream, int pack) {
   Plan p;
   SX_TRY(build_plan(d, p));
   Fp32WideScope fp32_scope(plan_wide_mode(p));
@@ -555,11 +563,32 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
     hipError_t e = hipMemsetAsync(at(ws, zb0), 0, (size_t)(zb1 - zb0), st);
     if (e != hipSuccess) return hip_fail(e, "memset(stats)");
   }
-  SX_TRY(sx_pack_input(dt, x, sb, sc, sh, sw, B, d->in_ch, d->H, d->W, at(ws, p.X0), p.in_pad, stream));
   // use_film == 2: encode and decode of this descriptor always see the same film_params, so every generator (the
   // decoder's too) is evaluated here in one launch and sx_unet_decode launches none
-  if (film) SX_TRY(film_run_forward(p, 0, d->use_film == 2 ? 2 * D + 1 : D + 1, params, ws, film_params, st,
-                                    film_clears ? (float*)at(ws, zb0) : nullptr, film_clears ? (int)((zb1 - zb0) / 4) : 0));
+  const int ngen = film ? (d->use_film == 2 ? 2 * D + 1 : D + 1) : 0;
+  bool head_done = false;
+  if (pack) {
+    std::vector<PackDesc> pk;
+    PackPad pad;
+    SX_TRY(pack_list(p, d, params, wpack, pk, pad));
+    FilmArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    if (ngen <= FILM_MAX_GEN) {
+      fa.zero = film_clears ? (float*)at(ws, zb0) : nullptr; fa.zero_n = film_clears ? (int)((zb1 - zb0) / 4) : 0;
+      fa.ngen = ngen; fa.B = B; fa.P = d->P; fa.Hf = d->film_hidden; fa.params = film_params;
+      for (int k = 0; k < ngen; ++k) film_fill(p, k, params, nullptr, ws, fa.g[k]);
+      const EncodeHeadExtra E = {fa, x, sb, sc, sh, sw, at(ws, p.X0), B, d->in_ch, d->H, d->W, p.in_pad};
+      const int rc = encode_head_launch(dt, pk.data(), (int)pk.size(), &pad, E, st);
+      if (rc < 0) return rc;
+      head_done = rc == 0;
+    }
+    if (!head_done) SX_TRY(pack_weights_multi(dt, pk.data(), (int)pk.size(), st, &pad));
+  }
+  if (!head_done) {
+    SX_TRY(sx_pack_input(dt, x, sb, sc, sh, sw, B, d->in_ch, d->H, d->W, at(ws, p.X0), p.in_pad, stream));
+    if (film) SX_TRY(film_run_forward(p, 0, ngen, params, ws, film_params, st,
+                                      film_clears ? (float*)at(ws, zb0) : nullptr, film_clears ? (int)((zb1 - zb0) / 4) : 0));
+  }
   for (int k = 0; k <= D; ++k) {
     bool pooled = false;
     SX_TRY(block_forward(p, k, params, wpack, ws, film, nullptr, st, k < D ? at(ws, p.Pool[k]) : nullptr, k < D ? p.C[k] : 0, &pooled));
@@ -567,6 +596,20 @@ extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params,
       SX_TRY(sx_maxpool2_forward(dt, B, p.H[k], p.W[k], p.C[k], at(ws, p.blk[k].O), 2 * p.C[k], at(ws, p.Pool[k]), p.C[k], stream));
   }
   return SX_OK;
+}
+
+extern "C" int sx_unet_encode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,
+                              const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                              const float* film_params, void* stream) {
+  return encode_impl(d, params, const_cast<void*>(wpack), ws, x, sb, sc, sh, sw, film_params, stream, 0);
+}
+
+// sx_unet_pack_weights + sx_unet_encode in one call: the weight packs, the input pack and the FiLM generators share a launch
+extern "C" int sx_unet_pack_encode(const sx_unet_desc* d, const float* const* params, void* wpack, void* ws,
+                                   const float* x, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                   const float* film_params, void* stream) {
+  SX_REQUIRE(params && wpack, "sx_unet_pack_encode: null pointer");
+  return encode_impl(d, params, wpack, ws, x, sb, sc, sh, sw, film_params, stream, 1);
 }
 
 extern "C" int sx_unet_decode(const sx_unet_desc* d, const float* const* params, const void* wpack, void* ws,

@@ -226,9 +226,8 @@ class TrainEngine:
         sess, bufs = self._session(B, H, W, fp is not None)
         lg = self.loss_opts["lam_grad"] if lam_grad is None else lam_grad
         begun = self._loss_begin(sess, bufs, mask, lg)
-        sess.pack_weights()
         masks, drop_table = self._drop_table(sess)
-        sess.encode(x, fp)
+        sess.pack_encode(x, fp)          # the weights changed in the last optimizer step: repack, in the encode head's launch
         sess.decode(fp, drop_table)
         out = self._loss_end(sess, bufs, y, begun, lg, True, 1.0 / max(int(grad_accum_steps), 1))
         # (sessions are film_shared: with FiLM on, this step's encode cleared the backward sums with the statistics)
