@@ -418,64 +418,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
 struct WgReduceArgs { WgReduceDesc d[WG_MAX_REDUCE]; int n; };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgReduceArgs A) {
-  // A WAVE owns a unit (256 contiguous bytes x all splits): lane = (split lane sl = lane / 16, e = lane % 16); a thread adds
-  // the float4 of splits sl, sl + 4, ... (independent loads, unrolled), the four split lanes are combined by two lane
-  // exchanges, lane (e, sl) stores element sl of the sum.  No LDS, no block barrier.  (Rounds 1-2: a BLOCK per unit, 16
-  // split lanes, one load per thread and two barriers per unit -- 6000 blocks of one unit each, 2.4 TB/s.)
   int di = 0;
   while (di + 1 < A.n && (int)blockIdx.x >= A.d[di + 1].blk0) ++di;
-  const WgReduceDesc& D = A.d[di];
-  const int64_t slab_sz = (int64_t)D.ntaps * D.CaPad * D.CbPad;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e = lane & 15, sl = lane >> 4;
-  const int A16 = D.CaPad >> 4, B16 = D.CbPad >> 4;
-  const int a16_n = D.a16_n ? D.a16_n : A16, tap_n = D.a16_n ? D.tap_n : D.ntaps;
-  const int bchunks = (D.Cb + 63) >> 6;
-  const int64_t nunits = D.tiled ? (int64_t)tap_n * a16_n * B16 * 4 : (int64_t)D.ntaps * D.Ca * bchunks;
-  for (int64_t u = ((int64_t)((int)blockIdx.x - D.blk0)) * 4 + wave; u < nunits; u += (int64_t)D.nblk * 4) {
-    const float* src;
-    int aa, bb, tap, tn;
-    bool ok;
-    if (D.tiled) {
-      // unit = four consecutive rows of one 16x16 tile; thread e: row 4q + e/4, cols (e%4)*4..+3
-      const int q = (int)(u & 3);
-      const int64_t tl = u >> 2;                                // (tap * a16_n + a16) * B16 + b16, local to this descriptor
-      const int b16 = (int)(tl % B16);
-      const int64_t ta = tl / B16;
-      const int a16 = (int)(ta % a16_n);
-      tap = (int)(ta / a16_n);
-      const int64_t tile = ((int64_t)(D.tap_lo + tap) * A16 + D.a16_lo + a16) * B16 + b16;
-      src = D.slab + (tile << 8) + q * 64 + e * 4;
-      aa = a16 * 16 + q * 4 + (e >> 2); bb = b16 * 16 + (e & 3) * 4 + sl; tn = tap_n;
-      ok = true;
-    } else {
-      // unit = 64 consecutive b of one (tap, a) row
-      const int bc = (int)(u % bchunks);
-      const int64_t row = u / bchunks;
-      aa = (int)(row % D.Ca); tap = (int)(row / D.Ca);
-      const int b = bc * 64 + e * 4;
-      src = D.slab + ((int64_t)tap * D.CaPad + aa) * D.CbPad + b;
-      bb = b + sl; tn = D.ntaps;
-      ok = b < D.CbPad;
-    }
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-#pragma unroll 4
-      for (int k = sl; k < D.nsplit; k += 4) s += *reinterpret_cast<const f32x4*>(src + k * slab_sz);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = s[r];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      s[r] = v;
-    }
-    if (aa < D.Ca && bb < D.Cb) {
-      const float t = sl == 0 ? s[0] : (sl == 1 ? s[1] : (sl == 2 ? s[2] : s[3]));
-      float* dst = D.out + ((int64_t)aa * D.Cb + bb) * tn + tap;
-      *dst = D.accumulate ? (*dst + t) : t;
-    }
-  }
+  wgrad_reduce_block(A.d[di], (int)blockIdx.x - A.d[di].blk0);
 }
 
 int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
@@ -485,11 +430,8 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st) {
     int blk = 0;
     for (int i = 0; i < A.n; ++i) {
       A.d[i] = descs[i0 + i];
-      const int64_t units = A.d[i].tiled ? (int64_t)(A.d[i].a16_n ? A.d[i].tap_n : A.d[i].ntaps) *
-                                               (A.d[i].a16_n ? A.d[i].a16_n : (A.d[i].CaPad >> 4)) * (A.d[i].CbPad >> 4) * 4
-                                         : (int64_t)A.d[i].ntaps * A.d[i].Ca * cdiv(A.d[i].Cb, 64);
       A.d[i].blk0 = blk;
-      A.d[i].nblk = (int)std::min<int64_t>((units + 3) / 4, 1024);      // four units (waves) per block
+      A.d[i].nblk = wgrad_reduce_blocks(A.d[i]);
       blk += A.d[i].nblk;
     }
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blk), dim3(256), 0, st, A);

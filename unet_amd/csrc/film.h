@@ -53,7 +53,10 @@ int film_forward(const FilmArgs& a, hipStream_t st);
 // wanted, no gradient w.r.t. the FiLM inputs) ONE launch runs the dW2 rows, the dW1 rows -- each block rebuilding the dpre
 // values of its 16 hidden units itself instead of waiting for a phase-A launch -- and these reductions: three dispatches
 // (film_bwd_a 15 us, film_bwd_b 20 us, gn_param_grad 12 us) become one.  Returns with *gn_done = 1 when they rode along.
+// rd (nullable): pending slab reductions of the same half (their split-K launch already enqueued): they join the launch too
+// when the table fits, *rd_done = 1.
+struct WgReduceDesc;
 int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st, const GnGradDesc* gn = nullptr, int n_gn = 0,
-                  int* gn_done = nullptr);
+                  int* gn_done = nullptr, const WgReduceDesc* rd = nullptr, int n_rd = 0, int* rd_done = nullptr);
 
 }  // namespace sx

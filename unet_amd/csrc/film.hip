@@ -3,6 +3,7 @@
 // (grid = samples x generators).  Tiny GEMVs: <0.01 % of the FLOPs, so plain FMA code.
 #include "sx_common.h"
 #include "film.h"
+#include "wgrad_common.h"
 #include <algorithm>
 #include <cstddef>
 
@@ -300,15 +301,33 @@ __global__ __launch_bounds__(256) void film_bwd_b_kernel(const FilmArgs) { film_
 
 // Training tail: rows y < ngen are the generators (dW2 rows and fused dW1 rows), the rows behind them run the GroupNorm affine /
 // bias gradient reductions of the same backward half.
-struct FilmTailArgs { FilmArgs f; GnGradArgs gn; int gn_blocks; };
+// ... and behind those, the slab reduction of the same half's weight gradients (round 3): it is independent of the generators,
+// and as a launch of its own (16 us) it ran while this one's 40 latency-bound blocks (33 us) had the chip to themselves.
+// Table sizes are what fits the 4 KB kernel-argument segment next to FilmArgs; larger halves take the separate launches.
+static constexpr int TAIL_GN = 20, TAIL_RED = 15;
+struct TailGn { GnGradDesc d[TAIL_GN]; int n, B, accumulate; };
+struct FilmTailArgs { FilmArgs f; TailGn gn; WgReduceDesc rd[TAIL_RED]; int gn_blocks, n_rd, rd_blocks; };
 static_assert(offsetof(FilmTailArgs, f) == 0, "the FiLM table leads the kernel arguments");
+static_assert(sizeof(FilmTailArgs) <= 4096, "kernel-argument segment");
 __global__ __launch_bounds__(256) void film_bwd_train_kernel(const FilmTailArgs) {
   typedef const FilmTailArgs __attribute__((address_space(4))) * TailK;      // FilmArgs sits at offset 0: the body finds it there
   TailK A = (TailK)__builtin_amdgcn_kernarg_segment_ptr();
   const int ngen = A->f.ngen;
   if ((int)blockIdx.y >= ngen) {
-    const int block = ((int)blockIdx.y - ngen) * (int)gridDim.x + (int)blockIdx.x;
-    if (block < A->gn_blocks) gn_param_grad_block(&A->gn, block);
+    int block = ((int)blockIdx.y - ngen) * (int)gridDim.x + (int)blockIdx.x;
+    if (block < A->gn_blocks) { gn_param_grad_block(&A->gn, block); return; }
+    block -= A->gn_blocks;
+    if (block < A->rd_blocks) {
+      int di = 0;
+      const int n = A->n_rd;
+      while (di + 1 < n && block >= A->rd[di + 1].blk0) ++di;
+      WgReduceDesc D;
+      D.slab = A->rd[di].slab; D.out = A->rd[di].out; D.nsplit = A->rd[di].nsplit; D.ntaps = A->rd[di].ntaps;
+      D.Ca = A->rd[di].Ca; D.Cb = A->rd[di].Cb; D.CaPad = A->rd[di].CaPad; D.CbPad = A->rd[di].CbPad;
+      D.accumulate = A->rd[di].accumulate; D.tiled = A->rd[di].tiled; D.a16_lo = A->rd[di].a16_lo; D.a16_n = A->rd[di].a16_n;
+      D.tap_lo = A->rd[di].tap_lo; D.tap_n = A->rd[di].tap_n; D.blk0 = A->rd[di].blk0; D.nblk = A->rd[di].nblk;
+      wgrad_reduce_block(D, block - D.blk0);
+    }
     return;
   }
   film_bwd_b_body<true>();
@@ -327,22 +346,36 @@ int film_forward(const FilmArgs& a, hipStream_t st) {
   return SX_OK;
 }
 
-int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st, const GnGradDesc* gn, int n_gn, int* gn_done) {
+int film_backward(const FilmArgs& a, bool weight_grads, hipStream_t st, const GnGradDesc* gn, int n_gn, int* gn_done,
+                  const WgReduceDesc* rd, int n_rd, int* rd_done) {
   if (gn_done) *gn_done = 0;
+  if (rd_done) *rd_done = 0;
   if (a.ngen <= 0) return SX_OK;
   static const int no_tail = env_int("SX_FILM_NO_TAIL", 0);        // A/B knob: the three-launch form
-  if (weight_grads && !a.dparams && n_gn <= GN_GRAD_MAX && !no_tail) {
-    static_assert(sizeof(FilmTailArgs) <= 4096, "kernel-argument segment");
+  static const int tail_reduce = env_int("SX_TAIL_REDUCE", 1);     // A/B knob: slab reduction inside the tail launch
+  if (weight_grads && !a.dparams && n_gn <= TAIL_GN && !no_tail) {
     FilmTailArgs T;
     T.f = a;
     memset(&T.gn, 0, sizeof(T.gn));
     T.gn.n = n_gn; T.gn.B = a.B; T.gn.accumulate = a.accumulate;
     for (int i = 0; i < n_gn; ++i) T.gn.d[i] = gn[i];
     T.gn_blocks = n_gn > 0 ? gn_param_grad_layout(T.gn) : 0;
+    T.n_rd = 0; T.rd_blocks = 0;
+    if (rd && rd_done && n_rd > 0 && n_rd <= TAIL_RED && tail_reduce) {
+      int blk = 0;
+      for (int i = 0; i < n_rd; ++i) {
+        T.rd[i] = rd[i];
+        T.rd[i].blk0 = blk;
+        T.rd[i].nblk = wgrad_reduce_blocks(T.rd[i]);
+        blk += T.rd[i].nblk;
+      }
+      T.n_rd = n_rd; T.rd_blocks = blk;
+      *rd_done = 1;
+    }
     int cmax = 0;
     for (int i = 0; i < a.ngen; ++i) cmax = std::max(cmax, a.g[i].C);
     const int gx = cdiv(2 * cmax + a.Hf, FR);
-    hipLaunchKernelGGL(film_bwd_train_kernel, dim3(gx, a.ngen + cdiv(T.gn_blocks, gx)), dim3(256), 0, st, T);
+    hipLaunchKernelGGL(film_bwd_train_kernel, dim3(gx, a.ngen + cdiv(T.gn_blocks + T.rd_blocks, gx)), dim3(256), 0, st, T);
     SX_LAUNCH_CHECK("film_bwd_train");
     if (gn_done) *gn_done = 1;
     return SX_OK;

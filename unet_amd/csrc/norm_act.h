@@ -15,7 +15,9 @@ struct GnGradArgs { GnGradDesc d[GN_GRAD_MAX]; int n, B, accumulate; };
 // blocks beside its own instead of paying a dispatch for them.
 // (the table is read from the kernel-argument segment: see film.hip)
 typedef const GnGradArgs __attribute__((address_space(4))) * GnGradArgsK;
-__device__ __forceinline__ void gn_param_grad_block(GnGradArgsK Ak, int block) {
+// (AK: any kernel-argument table with members d[], n, B, accumulate -- the training tail carries a shorter one)
+template <typename AK>
+__device__ __forceinline__ void gn_param_grad_block(AK Ak, int block) {
   __shared__ float gn_red[2][4][64];
   int di = 0;
   const int n = Ak->n;
@@ -45,7 +47,8 @@ __device__ __forceinline__ void gn_param_grad_block(GnGradArgsK Ak, int block) {
   }
 }
 // block ranges of a descriptor table; returns the number of blocks
-inline int gn_param_grad_layout(GnGradArgs& A) {
+template <typename ARGS>
+inline int gn_param_grad_layout(ARGS& A) {
   int blk = 0;
   for (int i = 0; i < A.n; ++i) { A.d[i].blk0 = blk; blk += (A.d[i].C + 63) / 64; }
   return blk;

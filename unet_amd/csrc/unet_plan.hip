@@ -241,7 +241,8 @@ static int film_run_forward(const Plan& p, int k0, int k1, const float* const* p
 }
 
 static int film_run_backward(const Plan& p, int k0, int k1, const float* const* params, float* const* grads, void* ws,
-                             const float* film_params, int flags, hipStream_t st, std::vector<GnGradDesc>* gn = nullptr) {
+                             const float* film_params, int flags, hipStream_t st, std::vector<GnGradDesc>* gn = nullptr,
+                             std::vector<WgReduceDesc>* rd = nullptr) {
   FilmArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.ngen = k1 - k0; fa.B = p.d.B; fa.P = p.d.P; fa.Hf = p.d.film_hidden; fa.params = film_params;
@@ -250,9 +251,11 @@ static int film_run_backward(const Plan& p, int k0, int k1, const float* const* 
   const bool wg = (flags & SX_BWD_WEIGHT_GRADS) != 0;
   for (int k = k0; k < k1; ++k) film_fill(p, k, params, wg ? grads : nullptr, ws, fa.g[k - k0]);
   // gn: this half's GroupNorm affine / bias gradient reductions ride on the FiLM launch when it takes them (training steps)
-  int done = 0;
-  SX_TRY(film_backward(fa, wg, st, gn ? gn->data() : nullptr, gn ? (int)gn->size() : 0, &done));
+  int done = 0, rdone = 0;
+  SX_TRY(film_backward(fa, wg, st, gn ? gn->data() : nullptr, gn ? (int)gn->size() : 0, &done,
+                       rd ? rd->data() : nullptr, rd ? (int)rd->size() : 0, &rdone));
   if (gn && done) gn->clear();
+  if (rd && rdone) rd->clear();      // the slab reductions of this half rode along too
   return SX_OK;
 }
 
@@ -290,7 +293,8 @@ struct WgQueue {
     d.sums = scratch; d.dgamma = db; d.dbeta = nullptr; d.C = C; d.blk0 = 0; d.nb = slots; d.stride = 1;
     gn.push_back(d);
   }
-  int flush() {
+  // reduce = false: the split-K launch only; the slab reductions stay in `pending` for a later launch to take (finish_reduce)
+  int flush(bool reduce = true) {
     if (!launches.empty()) {
       // longest BLOCKS first (estimated block time: arithmetic at 4 TFLOP/s per CU + operand bytes at 60 GB/s per CU, over
       // the problem's block count): the short ones fill the tail.  SX_WG_SORT_BLOCK=0: by whole-problem cost (rounds 1-2;
@@ -314,6 +318,10 @@ struct WgQueue {
       for (const WgReduceDesc& d : pending) bytes += (double)d.nsplit * (d.a16_n ? d.tap_n * d.a16_n * 16 : d.ntaps * d.CaPad) * d.CbPad * 4;
       fprintf(stderr, "[sx] weight-gradient slabs of this half: %zu problems, %.1f MB written + read\n", pending.size(), bytes / 1e6);
     }
+    if (!reduce) return SX_OK;
+    return finish_reduce();
+  }
+  int finish_reduce() {
     if (!pending.empty()) SX_TRY(wgrad_reduce_multi(pending.data(), (int)pending.size(), st));
     pending.clear();
     used = 0;
@@ -770,7 +778,8 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
   }
   const int ngen = (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1;
-  SX_TRY(wq.flush());
-  if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, st, &wq.gn));
-  return wq.finish_gn();        // whatever the FiLM launch did not take
+  SX_TRY(wq.flush(!film));      // with FiLM: the slab reductions try to ride on the training tail's launch
+  if (film) SX_TRY(film_run_backward(p, 0, ngen, params, grads, ws, film_params, flags, st, &wq.gn, &wq.pending));
+  SX_TRY(wq.finish_reduce());   // whatever the FiLM launch did not take
+  return wq.finish_gn();
 }
