@@ -459,11 +459,14 @@ struct FinalArgs {
 };
 // One block: total the numerator slots (fixed order), write out[0..3], and leave the slots ZERO for the next call (the
 // single-scale path has no memset launch: sx_loss_prepare's reduction kernel zeroes them the first time).
+// COHERENT: the slots were filled by atomics of THIS launch (other XCDs' included): read them where atomics are performed
+template <bool COHERENT = false>
 __device__ __forceinline__ void loss_final_block(const FinalArgs& a) {
   __shared__ float tot[16];
   if (threadIdx.x < 16) {
     float t = 0.f;
-    for (int sl = 0; sl < NSLOT; ++sl) t += a.num[sl * SLOT_STRIDE + threadIdx.x];
+    for (int sl = 0; sl < NSLOT; ++sl)
+      t += COHERENT ? atomicAdd(a.num + sl * SLOT_STRIDE + threadIdx.x, 0.0f) : a.num[sl * SLOT_STRIDE + threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
@@ -601,7 +604,10 @@ struct TileArgs {
   int magnitude, gkind;     // gradient term: compare magnitudes / components; its pixel loss kind
   float cgl;                // lam_grad
   int tiles_x, tiles_y;
+  FinalArgs fin;            // ticket != 0: the last block to arrive totals the loss value (no one-block launch behind this one)
+  int ticket;
 };
+static constexpr int TICKET_SLOT = 16;      // an unused word of numerator slot 0 (zeroed with the slots)
 
 // Block = LT_NT threads for LT_GH x LT_GW windows x 4 channels: a thread owns ONE window x 2 channels (the first version,
 // 256 threads with two windows x 4 channels each, took 37 us: ~3000 VALU instructions per thread on two waves per SIMD).
@@ -779,12 +785,22 @@ __global__ __launch_bounds__(LT_NT) void loss_tile_kernel(TileArgs A) {
   const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   __shared__ float red[4 * (LT_NT / 64)];
   block_sum<4>(v, red);
-  if (threadIdx.x == 0 && c0 < a.C) {
-    float* num = a.num + (lin & (NSLOT - 1)) * SLOT_STRIDE;
-    atomicAdd(num + 0, v[0]);
-    atomicAdd(num + 1, v[1]);
-    atomicAdd(num + 2, v[2]);
-    atomicAdd(num + 3, v[3]);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    float back = 0.f;
+    if (c0 < a.C) {
+      float* num = a.num + (lin & (NSLOT - 1)) * SLOT_STRIDE;
+      // returning atomics: their old values are in hand only once the additions have been performed
+      back = atomicAdd(num + 0, v[0]) + atomicAdd(num + 1, v[1]) + atomicAdd(num + 2, v[2]) + atomicAdd(num + 3, v[3]);
+    }
+    int last = 0;
+    if (A.ticket) {
+      unsigned one = 1u;
+      asm volatile("" : "+v"(one) : "v"(back));      // the ticket is drawn after those returns (no fence: nothing else is published)
+      const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+      last = atomicAdd(reinterpret_cast<unsigned*>(a.num + TICKET_SLOT), one) == nblk - 1;
+    }
+    s_last = last;
   }
   if (a.bias_sums && c0 < a.C) {
     // waves 0..7 hold channel pair 0, waves 8..15 pair 1 (NWIN = 512 threads each)
@@ -803,6 +819,8 @@ __global__ __launch_bounds__(LT_NT) void loss_tile_kernel(TileArgs A) {
       atomicAdd(a.bias_sums + (lin % SX_HEAD_BIAS_SLOTS) * a.C + c0 + threadIdx.x, t);
     }
   }
+  __syncthreads();
+  if (s_last) loss_final_block<true>(A.fin);      // every block has arrived: total the slots, write out[0..3], zero slots and ticket
 }
 
 // fine[p] += coarse[q(p)] / 4   (avg_pool2d(2) backward), floor semantics: trailing odd row/col untouched
@@ -982,6 +1000,8 @@ extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int
       ta.f = fa; ta.f.g = nullptr;
       ta.mg = ws + L.MG[0]; ta.magnitude = grad_magnitude; ta.gkind = grad_kind; ta.cgl = lam_grad;
       ta.tiles_x = cdiv(gw, LT_GW); ta.tiles_y = cdiv(gh, LT_GH);
+      static const int ticket = env_int("SX_LOSS_TICKET", 1);     // A/B knob: 0 = a one-block launch totals the loss value
+      ta.fin = f; ta.ticket = ticket;
       if (bias_sums) {
         ta.f.bias_sums = bias_sums;
         if (bias_done) *bias_done = 1;
@@ -989,7 +1009,7 @@ extern "C" int sx_loss_forward_backward_bias(int dtype, int B, int C, int H, int
       const dim3 grid(ta.tiles_x * ta.tiles_y, B, 2);
       if (dtype == SX_BF16) hipLaunchKernelGGL(loss_tile_kernel<bf16>, grid, dim3(LT_NT), 0, st, ta);
       else hipLaunchKernelGGL(loss_tile_kernel<float>, grid, dim3(LT_NT), 0, st, ta);
-      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+      if (!ticket) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, f);
       SX_LAUNCH_CHECK("loss_forward_backward");
       return SX_OK;
     }
