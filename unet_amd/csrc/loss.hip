@@ -463,10 +463,20 @@ struct FinalArgs {
 template <bool COHERENT = false>
 __device__ __forceinline__ void loss_final_block(const FinalArgs& a) {
   __shared__ float tot[16];
-  if (threadIdx.x < 16) {
+  if constexpr (COHERENT) {
+    // one atomic read per thread (a loop over the 64 slots would be 64 dependent round trips), then the same fixed-order sum
+    __shared__ float got[NSLOT][16];
+    for (int i = threadIdx.x; i < NSLOT * 16; i += blockDim.x)
+      got[i >> 4][i & 15] = atomicAdd(a.num + (i >> 4) * SLOT_STRIDE + (i & 15), 0.0f);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float t = 0.f;
+      for (int sl = 0; sl < NSLOT; ++sl) t += got[sl][threadIdx.x];
+      tot[threadIdx.x] = t;
+    }
+  } else if (threadIdx.x < 16) {
     float t = 0.f;
-    for (int sl = 0; sl < NSLOT; ++sl)
-      t += COHERENT ? atomicAdd(a.num + sl * SLOT_STRIDE + threadIdx.x, 0.0f) : a.num[sl * SLOT_STRIDE + threadIdx.x];
+    for (int sl = 0; sl < NSLOT; ++sl) t += a.num[sl * SLOT_STRIDE + threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
