@@ -6,7 +6,6 @@ Algorithmic bytes = every tensor the kernel must read once + write once (SURVEY 
 import re, sqlite3, sys
 
 B, PEAK = 64, 8000.0
-T = [B * (128 >> l) * (64 >> l) * (32 << l) * 2 for l in range(4)]          # bytes of one bf16 feature map per level
 LEVELS = [0, 1, 2, 3, 2, 1, 0]                                                # block order, forward and backward
 NPARAM = 2_199_720
 
@@ -15,6 +14,9 @@ rows = c.execute("select name, start, end from kernels order by start").fetchall
 idx = [i for i, r in enumerate(rows) if "adamw" in r[0]]
 nsteps = min(10, len(idx) - 1)
 per = idx[-1] - idx[-2]
+# element size of the activations: the fp32 tier's kernels are the <float, ...> instantiations
+ESZ = 4 if any("_kernel<float" in r[0] or "IfLi" in r[0] or "IfEE" in r[0] for r in rows[idx[-2]:idx[-1]]) else 2
+T = [B * (128 >> l) * (64 >> l) * (32 << l) * ESZ for l in range(4)]        # bytes of one feature map per level
 
 def avg(pos):
     d = [rows[idx[-k - 1] + 1 + pos][2] - rows[idx[-k - 1] + 1 + pos][1] for k in range(1, nsteps + 1)]
@@ -41,7 +43,7 @@ for pos, name in step:
             fwd_in_block = 1
         else:
             if k == "act_fwd_pool":
-                byt, what = 3.375 * T[lvl], f"block out + max-pool   L{lvl}: read Y,S, write O,O/4,positions"
+                byt, what = (3.25 + 0.25 / ESZ) * T[lvl], f"block out + max-pool   L{lvl}: read Y,S, write O,O/4,positions"
             else:
                 byt, what = 3 * T[lvl], f"block out fwd          L{lvl}: read Y,S, write O"
             fwd_in_block = 0
@@ -67,7 +69,7 @@ for pos, name in step:
             bblk += 1
     elif k in ("maxpool_bwd_add", "maxpool_bwd_add_idx"):
         lvl = [2, 1, 0][pool_b]; pool_b += 1
-        if k.endswith("idx"): byt, what = 2.375 * T[lvl], f"max-pool bwd + skip    L{lvl}: read positions,dskip,dP, write dO"
+        if k.endswith("idx"): byt, what = (2.25 + 0.25 / ESZ) * T[lvl], f"max-pool bwd + skip    L{lvl}: read positions,dskip,dP, write dO"
         else: byt, what = 3.25 * T[lvl], f"max-pool bwd + skip    L{lvl}: read O,dskip,dP, write dO"
     elif k == "maxpool_fwd":
         lvl = [0, 1, 2][pool_f]; pool_f += 1
@@ -81,7 +83,7 @@ for pos, name in step:
     elif k == "grad_out":
         byt, what = B * 128 * 64 * (8 * 4 + 8 * 2) + 2 * B * 64 * 32 * 8 * 4, "loss: transposed Sobel + NHWC gradient write"
     elif k == "loss_tile":
-        byt, what = B * 128 * 64 * (8 * 2 + 8 * 4 + 4 + 8 * 2) + 4 * B * 64 * 32, "loss, one tile kernel: read pred, target, mask, pooled mask; write d(pred)"
+        byt, what = B * 128 * 64 * (8 * ESZ + 8 * 4 + 4 + 8 * ESZ) + 4 * B * 64 * 32, "loss, one tile kernel: read pred, target, mask, pooled mask; write d(pred)"
     elif k == "sobel_fwd":
         byt, what = 6 * B * 64 * 32 * 8 * 4, "loss: Sobel of pooled pred/target + its gradient"
     elif k == "wgrad_reduce_multi":
@@ -89,7 +91,7 @@ for pos, name in step:
     if byt is not None:
         gbs = byt / us / 1e3
         out.append(f"{pos:4d} {k:18s} {us:7.2f} us  {byt/1e6:8.1f} MB  {gbs:7.0f} GB/s  {100*gbs/PEAK:5.1f} %   {what}")
-print(f"# element-wise / pooling / loss / optimizer kernels of one training step, avg over the last {nsteps} steps of the trace")
+print(f"# element-wise / pooling / loss / optimizer kernels of one training step ({'fp32' if ESZ == 4 else 'bf16'} activations), avg over the last {nsteps} steps of the trace")
 print(f"# achieved = algorithmic bytes / kernel time; peak 8000 GB/s (practical streaming rate on this part: 4.5-5 TB/s;")
 print(f"# figures above that are re-reads served by the 256 MB MALL)")
 print("# pos kernel              time       bytes      achieved   of peak  what")
