@@ -20,18 +20,6 @@
 
 namespace sx {
 
-struct WgradArgs {
-  const void* P; const void* Q; float* slab;
-  int B, H, W;          // P pixel grid
-  int Hq, Wq;           // Q pixel dims
-  int p_ld, q_ld;
-  int Ca, Cb, CaPad, CbPad;
-  int ntaps, tapw, q_scale, pad;
-  int tw_log2, TW, TH, LW, LH, TP;   // TP = pixels per tile (multiple of 32)
-  int tiles_x, tiles_y, ntiles, tiles_per_split;
-  int nbf;              // b fragments (16 channels) in this block's b tile
-};
-
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16> { static constexpr int PADB = 16; };
 template <> struct WgTraits<float> { static constexpr int PADB = 64; };
@@ -251,23 +239,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // into registers under this tile's MFMAs.
 // NW waves per block: the 36 items of a 64 x 64 x 9 problem take 9 x 16 accumulator registers per wave on four waves (spills at
 // two blocks per CU); on eight waves they take 5 x 16.
-template <int MI, int ITEMS, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(WgradArgs a) {
+// DB: two LDS images; the planes of tile t+1 are written while other waves still multiply tile t (one barrier per tile).
+// The multi-problem launch's blocks have a CU to themselves (eight waves), so nothing else overlaps their staging.
+template <int MI, int ITEMS, int NW, bool DB = false>
+__device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int blk_y, int blk_z) {
   constexpr int NT = NW * 64;
   constexpr int BA = MI * 16, BB = 64;
   constexpr int PROW = BA * 2 + 16, QROW = BB * 2 + 16;
   constexpr int PPIECES = BA / 4, QPIECES = BB / 4;        // 16-byte pieces of 4 fp32 per pixel
   constexpr int NPP = 1024 / NT, NPQ = (MI == 2 ? 3072 : 2048) / NT;      // MI = 2 also takes 128-pixel tiles (180-pixel halo)
   extern __shared__ __align__(16) char smem[];
-  char* sPh = smem;
-  char* sPl = sPh + a.TP * PROW;
-  char* sQh = sPl + a.TP * PROW;
-  char* sQl = sQh + a.LH * a.LW * QROW;
+  const int p_img = a.TP * PROW, q_img = a.LH * a.LW * QROW;      // one plane of each operand
+  const int buf_bytes = 2 * (p_img + q_img);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
-  const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
-  const int split = blockIdx.z;
+  const int a0 = blk_x * BA, b0 = blk_y * BB;
+  const int split = blk_z;
   const int nitems = a.ntaps * a.nbf;
 
   int it_tap_off[ITEMS], it_bf[ITEMS];
@@ -340,10 +328,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
     *reinterpret_cast<bf16x4*>(hi_img + off) = h;
     *reinterpret_cast<bf16x4*>(lo_img + off) = l;
   };
-  fetch(t_begin);
   const int q4 = n >> 2, p4 = n & 3;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    __syncthreads();
+  auto put_tile = [&](char* buf) {
+    char* sPh = buf;
+    char* sPl = sPh + p_img;
+    char* sQh = sPl + p_img;
+    char* sQl = sQh + q_img;
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
       const int p = tid + i * NT;
@@ -354,7 +344,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
       const int p = tid + i * NT;
       if (p < np_q) put(sQh, sQl, (p / QPIECES) * QROW + (p % QPIECES) * 8, pre_q[i]);
     }
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  if constexpr (DB) {
+    if (t_begin < t_end) put_tile(smem);
     __syncthreads();
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    char* buf = DB ? smem + ((tile - t_begin) & 1) * buf_bytes : smem;
+    if constexpr (!DB) {
+      __syncthreads();
+      put_tile(buf);
+      __syncthreads();
+    }
+    char* sPh = buf;
+    char* sPl = sPh + p_img;
+    char* sQh = sPl + p_img;
+    char* sQl = sQh + q_img;
     if (tile + 1 < t_end) fetch(tile + 1);
     for (int ks = 0; ks < (a.TP >> 5); ++ks) {
       // this lane supplies rows k = ks*32 + 8g + 4jb + q4, jb = 0,1
@@ -391,6 +397,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (DB) {
+      // the other image was last read in the previous iteration, which every wave left through the barrier below
+      if (tile + 1 < t_end) put_tile(smem + (((tile - t_begin) & 1) ^ 1) * buf_bytes);
+      __syncthreads();
+    }
   }
 
   float* slab = a.slab + (int64_t)split * a.ntaps * a.CaPad * a.CbPad;
@@ -408,6 +419,42 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(Wgra
         if (arow < a.CaPad && bcol < a.CbPad)
           slab[((int64_t)tap * a.CaPad + arow) * a.CbPad + bcol] = acc[t][j][r];
       }
+  }
+}
+
+template <int MI, int ITEMS, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad_x3_kernel(WgradArgs a) {
+  wgrad_x3_body<MI, ITEMS, NW>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Every fp32-tier problem of a backward half in ONE launch (the bf16 tier's wgrad_ws_multi_kernel, applied to this kernel):
+// block ranges per problem, all on eight waves (the item count per wave follows from taps x b fragments), longest blocks first.
+static constexpr int WG_X3_MULTI_MAX = 16;
+struct WgX3MultiArgs {
+  WgradArgs p[WG_X3_MULTI_MAX];
+  int variant[WG_X3_MULTI_MAX], a_tiles[WG_X3_MULTI_MAX], ab_tiles[WG_X3_MULTI_MAX];
+  int blk0[WG_X3_MULTI_MAX + 1];
+  int n;
+};
+static_assert(sizeof(WgX3MultiArgs) <= 4096, "kernel-argument segment");
+#define SX_X3_VARIANTS(X) X(2, 1) X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(4, 1) X(4, 2) X(4, 3) X(4, 4) X(4, 5)
+__global__ __launch_bounds__(512, 1) void wgrad_x3_multi_kernel(const WgX3MultiArgs) {
+  typedef const WgX3MultiArgs __attribute__((address_space(4))) * TablePtr;      // (see wgrad_ws_multi_kernel)
+  TablePtr A = (TablePtr)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+  const int n = A->n;
+  while (pi + 1 < n && (int)blockIdx.x >= A->blk0[pi + 1]) ++pi;
+  const int id = (int)blockIdx.x - A->blk0[pi];
+  WgradArgs a;
+  __builtin_memcpy(&a, &A->p[pi], sizeof(a));
+  const int at = A->a_tiles[pi], ab = A->ab_tiles[pi];
+  const int split = id / ab, r = id - split * ab;
+  const int by = r / at, bx = r - by * at;
+  switch (A->variant[pi]) {
+#define SX_X3_BODY(mi, items) case mi * 16 + items: wgrad_x3_body<mi, items, 8, true>(a, bx, by, split); break;
+    SX_X3_VARIANTS(SX_X3_BODY)
+#undef SX_X3_BODY
+    default: break;
   }
 }
 
@@ -553,6 +600,29 @@ static int wgrad_items_x3(const WgradArgs& a, const WgPlan& p, hipStream_t st) {
   return SX_ERR_UNSUPPORTED;
 }
 
+int wgrad_x3_launch(WgX3Launch* l, int n, hipStream_t st) {
+  std::stable_sort(l, l + n, [](const WgX3Launch& x, const WgX3Launch& y) { return x.cost > y.cost; });
+  static std::atomic<unsigned long long> done{0};
+  SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(wgrad_x3_multi_kernel), done, "hipFuncSetAttribute(wgrad_x3_multi)"));
+  for (int i0 = 0; i0 < n; i0 += WG_X3_MULTI_MAX) {
+    WgX3MultiArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = std::min(WG_X3_MULTI_MAX, n - i0);
+    int blk = 0, smem = 0;
+    for (int i = 0; i < A.n; ++i) {
+      const WgX3Launch& x = l[i0 + i];
+      A.p[i] = x.a; A.variant[i] = x.variant; A.a_tiles[i] = x.a_tiles; A.ab_tiles[i] = x.a_tiles * x.b_tiles;
+      A.blk0[i] = blk;
+      blk += x.a_tiles * x.b_tiles * x.nsplit;
+      smem = std::max(smem, 2 * x.smem);      // two images per block
+    }
+    A.blk0[A.n] = blk;
+    hipLaunchKernelGGL(wgrad_x3_multi_kernel, dim3(blk), dim3(512), (size_t)smem, st, A);
+    SX_LAUNCH_CHECK("wgrad_x3_multi");
+  }
+  return SX_OK;
+}
+
 }  // namespace sx
 
 using namespace sx;
@@ -568,7 +638,8 @@ extern "C" int64_t sx_conv_wgrad_workspace_bytes(int mode, int B, int H, int W, 
 
 namespace sx {
 int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
-                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer) {
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer,
+                 WgX3Launch* defer_x3) {
   SX_REQUIRE(P && Q && slab && desc, "sx_conv_wgrad: null pointer");
   SX_REQUIRE(dtype == SX_F32 || dtype == SX_BF16, "sx_conv_wgrad: bad dtype %d", dtype);
   const int EPL = dtype == SX_BF16 ? 8 : 4;
@@ -607,13 +678,34 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
     SX_TRY(wgrad_geom(mode, dtype, B, H, W, a, x3_tp));
     if (a.LH * a.LW * 16 > 12 * 256 || a.TP % 32) SX_TRY(wgrad_geom(mode, dtype, B, H, W, a));      // 4-wide grids: the halo of a 32 x 4 tile exceeds the staging slots
   }
-  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && wsplit) ? x3_blocks : 1024);
+  // a problem that will share its launch with the rest of its backward half need not fill the chip alone: fewer, longer
+  // splits (less slab traffic), SX_X3_WG_BATCH_BLOCKS per problem
+  static const int x3_multi = env_int("SX_X3_WG_MULTI", 1), x3_batch_blocks = env_int("SX_X3_WG_BATCH_BLOCKS", 128);
+  const bool batch = defer_x3 && dtype == SX_F32 && wsplit && x3_multi;
+  WgPlan p = wgrad_plan(mode, B, H, W, Ca, Cb, a, (dtype == SX_F32 && wsplit) ? (batch ? x3_batch_blocks : x3_blocks) : 1024);
   SX_REQUIRE((int64_t)p.ws_bytes <= slab_bytes, "sx_conv_wgrad: workspace too small (%lld < %zu)",
              (long long)slab_bytes, p.ws_bytes);
   a.P = P; a.Q = Q; a.slab = (float*)slab;
   a.B = B; a.H = H; a.W = W; a.Hq = Hq; a.Wq = Wq; a.p_ld = p_ld; a.q_ld = q_ld;
   a.Ca = Ca; a.Cb = Cb; a.CaPad = round_up(Ca, 16); a.CbPad = round_up(Cb, 16);
   a.nbf = p.nbf; a.tiles_per_split = p.tiles_per_split;
+  if (batch) {
+    const int PROW = p.MI * 16 * 2 + 16, QROW = 64 * 2 + 16;
+    const size_t smem = 2 * ((size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW);
+    const int items8 = cdiv(a.ntaps * p.nbf, 8);
+    const bool fits = 2 * smem <= 160 * 1024 && a.TP * p.MI * 4 <= 4 * 256 && a.LH * a.LW * 16 <= (p.MI == 2 ? 12 : 8) * 256 &&
+                      a.TP % 32 == 0 && items8 >= 1 && items8 <= 5;
+    if (fits) {
+      defer_x3->a = a; defer_x3->variant = p.MI * 16 + items8;
+      defer_x3->a_tiles = p.a_tiles; defer_x3->b_tiles = p.b_tiles; defer_x3->nsplit = p.nsplit; defer_x3->smem = (int)smem;
+      // one block: its tiles' MFMA work at 4 TFLOP/s per CU + its operand bytes at 60 GB/s per CU
+      const double px = (double)p.tiles_per_split * a.TP;
+      defer_x3->cost = 3.0 * 2.0 * px * a.ntaps * (p.MI * 16) * (p.nbf * 16) / 4e12 +
+                       4.0 * p.tiles_per_split * ((double)a.TP * p.MI * 16 + (double)a.LH * a.LW * 64) / 6e10;
+      desc->slab = (const float*)slab; desc->nsplit = p.nsplit; desc->ntaps = a.ntaps; desc->CaPad = a.CaPad; desc->CbPad = a.CbPad;
+      return WG_DEFERRED_X3;
+    }
+  }
   int rc;
   if (dtype == SX_BF16) rc = p.MI == 4 ? wgrad_items<bf16, 4>(a, p, st) : wgrad_items<bf16, 2>(a, p, st);
   else if (wsplit) rc = p.MI == 4 ? wgrad_items_x3<4>(a, p, st) : wgrad_items_x3<2>(a, p, st);

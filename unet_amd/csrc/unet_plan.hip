@@ -268,6 +268,7 @@ struct WgQueue {
   char* base; int64_t cap, used; int dtype, B, acc;
   hipStream_t st;
   std::vector<WgWsLaunch> launches;   // persistent-tier problems not launched yet
+  std::vector<WgX3Launch> x3;         // fp32-tier problems not launched yet
   std::vector<WgReduceDesc> pending;  // slabs not reduced yet
   std::vector<GnGradDesc> gn;         // GroupNorm affine gradients, reduced over the batch in one launch at the end
   WgQueue(const Plan& p, void* ws, int acc_, hipStream_t st_)
@@ -311,6 +312,10 @@ struct WgQueue {
       });
       SX_TRY(wgrad_ws_launch(launches.data(), (int)launches.size(), st));
       launches.clear();
+    }
+    if (!x3.empty()) {
+      SX_TRY(wgrad_x3_launch(x3.data(), (int)x3.size(), st));
+      x3.clear();
     }
     static const int report = env_int("SX_WG_REPORT", 0);        // diagnostic: slab bytes of this half (tools/wgrad_slabs.sh)
     if (report) {
@@ -359,8 +364,10 @@ struct WgQueue {
     WgReduceDesc d;
     memset(&d, 0, sizeof(d));
     WgWsLaunch l;
-    const int rc = wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, base + used, cap - used, &d, st, &l);
+    WgX3Launch lx;
+    const int rc = wgrad_launch(dtype, mode, B, H, W, Ca, Cb, P, p_ld, Q, q_ld, Hq, Wq, base + used, cap - used, &d, st, &l, &lx);
     if (rc == WG_DEFERRED) launches.push_back(l);
+    else if (rc == WG_DEFERRED_X3) x3.push_back(lx);
     else SX_TRY(rc);
     d.out = dw; d.Ca = Ca_out; d.Cb = Cb_out; d.accumulate = acc;
     pending.push_back(d);

@@ -91,9 +91,28 @@ int wgrad_reduce_multi(const WgReduceDesc* descs, int n, hipStream_t st);
 // `defer` (nullable): a problem the persistent bf16 tier covers is not launched but described in *defer, and the call
 // returns WG_DEFERRED; the caller launches a batch of them with wgrad_ws_launch (before reducing).
 struct WgWsLaunch;
-static constexpr int WG_DEFERRED = 2;
+struct WgX3Launch;
+static constexpr int WG_DEFERRED = 2, WG_DEFERRED_X3 = 3;
+// `defer_x3` (nullable): the same for the fp32 tier's split-bf16 kernel (WG_DEFERRED_X3, wgrad_x3_launch)
 int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const void* P, int p_ld, const void* Q,
-                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer);
+                 int q_ld, int Hq, int Wq, void* slab, int64_t slab_bytes, WgReduceDesc* desc, hipStream_t st, WgWsLaunch* defer,
+                 WgX3Launch* defer_x3 = nullptr);
+
+// arguments of the generic split-K kernels (conv_wgrad.hip)
+struct WgradArgs {
+  const void* P; const void* Q; float* slab;
+  int B, H, W;          // P pixel grid
+  int Hq, Wq;           // Q pixel dims
+  int p_ld, q_ld;
+  int Ca, Cb, CaPad, CbPad;
+  int ntaps, tapw, q_scale, pad;
+  int tw_log2, TW, TH, LW, LH, TP;   // TP = pixels per tile (multiple of 32)
+  int tiles_x, tiles_y, ntiles, tiles_per_split;
+  int nbf;              // b fragments (16 channels) in this block's b tile
+};
+// A prepared fp32-tier problem: blocks = a_tiles * b_tiles * nsplit of 512 threads, `cost` = estimated time of one block
+struct WgX3Launch { WgradArgs a; int variant, a_tiles, b_tiles, nsplit, smem; double cost; };
+int wgrad_x3_launch(WgX3Launch* l, int n, hipStream_t st);      // (sorts l: longest blocks first)
 
 struct WgWsArgs {
   const bf16* P; const bf16* Q; float* slab;
