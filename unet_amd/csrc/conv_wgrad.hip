@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // into registers under this tile's MFMAs.
 // NW waves per block: the 36 items of a 64 x 64 x 9 problem take 9 x 16 accumulator registers per wave on four waves (spills at
 // two blocks per CU); on eight waves they take 5 x 16.
-// DB: two LDS images; the planes of tile t+1 are written while other waves still multiply tile t (one barrier per tile).
-// The multi-problem launch's blocks have a CU to themselves (eight waves), so nothing else overlaps their staging.
-template <int MI, int ITEMS, int NW, bool DB = false>
+// (Measured for the eight-wave multi-problem launch and dropped: a second LDS image with one barrier per tile, 3.645 against
+// 3.645-3.65 ms per fp32 step; plus a second register set, loads two tiles ahead: 3.913 against 3.902 ms in one box.)
+template <int MI, int ITEMS, int NW>
 __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int blk_y, int blk_z) {
   constexpr int NT = NW * 64;
   constexpr int BA = MI * 16, BB = 64;
@@ -250,7 +250,6 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
   constexpr int NPP = 1024 / NT, NPQ = (MI == 2 ? 3072 : 2048) / NT;      // MI = 2 also takes 128-pixel tiles (180-pixel halo)
   extern __shared__ __align__(16) char smem[];
   const int p_img = a.TP * PROW, q_img = a.LH * a.LW * QROW;      // one plane of each operand
-  const int buf_bytes = 2 * (p_img + q_img);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -280,7 +279,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
   const float* __restrict__ Qg = reinterpret_cast<const float*>(a.Q);
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
-  f32x4 pre_p[NPP], pre_q[NPQ];
+  struct Pre { f32x4 p[NPP]; f32x4 q[NPQ]; };      // one tile's pieces on their way from HBM to LDS
   int pp_y[NPP], pp_x[NPP], pq_y[NPQ], pq_x[NPQ];
   const int np_p = a.TP * PPIECES, np_q = a.LH * a.LW * QPIECES;
 #pragma unroll
@@ -295,7 +294,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
     pq_y[i] = p < np_q ? r / a.LW : (1 << 28);
     pq_x[i] = r - (r / a.LW) * a.LW;
   }
-  auto fetch = [&](int tile) {
+  auto fetch = [&](Pre& R, int tile) {
     int tt = tile;
     const int tx_i = tt % a.tiles_x; tt /= a.tiles_x;
     const int ty_i = tt % a.tiles_y; tt /= a.tiles_y;
@@ -309,7 +308,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (py < a.H && px < a.W && c < a.Ca)
         v = *reinterpret_cast<const f32x4*>(Pg + ((int64_t)(bimg * a.H + py) * a.W + px) * a.p_ld + c);
-      pre_p[i] = v;
+      R.p[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NPQ; ++i) {
@@ -318,7 +317,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq && c < a.Cb)
         v = *reinterpret_cast<const f32x4*>(Qg + ((int64_t)(bimg * a.Hq + qy) * a.Wq + qx) * a.q_ld + c);
-      pre_q[i] = v;
+      R.q[i] = v;
     }
   };
   auto put = [&](char* hi_img, char* lo_img, int off, const f32x4& v) {
@@ -329,7 +328,7 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
     *reinterpret_cast<bf16x4*>(lo_img + off) = l;
   };
   const int q4 = n >> 2, p4 = n & 3;
-  auto put_tile = [&](char* buf) {
+  auto put_tile = [&](const Pre& R, char* buf) {
     char* sPh = buf;
     char* sPl = sPh + p_img;
     char* sQh = sPl + p_img;
@@ -337,31 +336,19 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
       const int p = tid + i * NT;
-      if (p < np_p) put(sPh, sPl, (p / PPIECES) * PROW + (p % PPIECES) * 8, pre_p[i]);
+      if (p < np_p) put(sPh, sPl, (p / PPIECES) * PROW + (p % PPIECES) * 8, R.p[i]);
     }
 #pragma unroll
     for (int i = 0; i < NPQ; ++i) {
       const int p = tid + i * NT;
-      if (p < np_q) put(sQh, sQl, (p / QPIECES) * QROW + (p % QPIECES) * 8, pre_q[i]);
+      if (p < np_q) put(sQh, sQl, (p / QPIECES) * QROW + (p % QPIECES) * 8, R.q[i]);
     }
   };
-  if (t_begin < t_end) fetch(t_begin);
-  if constexpr (DB) {
-    if (t_begin < t_end) put_tile(smem);
-    __syncthreads();
-  }
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    char* buf = DB ? smem + ((tile - t_begin) & 1) * buf_bytes : smem;
-    if constexpr (!DB) {
-      __syncthreads();
-      put_tile(buf);
-      __syncthreads();
-    }
-    char* sPh = buf;
-    char* sPl = sPh + p_img;
-    char* sQh = sPl + p_img;
-    char* sQl = sQh + q_img;
-    if (tile + 1 < t_end) fetch(tile + 1);
+  auto mma_tile = [&](const char* buf) {
+    const char* sPh = buf;
+    const char* sPl = sPh + p_img;
+    const char* sQh = sPl + p_img;
+    const char* sQl = sQh + q_img;
     for (int ks = 0; ks < (a.TP >> 5); ++ks) {
       // this lane supplies rows k = ks*32 + 8g + 4jb + q4, jb = 0,1
       const int k0 = ks * 32 + 8 * g + q4, k1 = k0 + 4;
@@ -397,11 +384,15 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradArgs& a, int blk_x, int
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if constexpr (DB) {
-      // the other image was last read in the previous iteration, which every wave left through the barrier below
-      if (tile + 1 < t_end) put_tile(smem + (((tile - t_begin) & 1) ^ 1) * buf_bytes);
-      __syncthreads();
-    }
+  };
+  Pre R;
+  if (t_begin < t_end) fetch(R, t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();
+    put_tile(R, smem);
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(R, tile + 1);
+    mma_tile(smem);
   }
 
   float* slab = a.slab + (int64_t)split * a.ntaps * a.CaPad * a.CbPad;
@@ -451,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_x3_multi_kernel(const WgX3MultiA
   const int split = id / ab, r = id - split * ab;
   const int by = r / at, bx = r - by * at;
   switch (A->variant[pi]) {
-#define SX_X3_BODY(mi, items) case mi * 16 + items: wgrad_x3_body<mi, items, 8, true>(a, bx, by, split); break;
+#define SX_X3_BODY(mi, items) case mi * 16 + items: wgrad_x3_body<mi, items, 8>(a, bx, by, split); break;
     SX_X3_VARIANTS(SX_X3_BODY)
 #undef SX_X3_BODY
     default: break;
@@ -604,17 +595,18 @@ int wgrad_x3_launch(WgX3Launch* l, int n, hipStream_t st) {
   std::stable_sort(l, l + n, [](const WgX3Launch& x, const WgX3Launch& y) { return x.cost > y.cost; });
   static std::atomic<unsigned long long> done{0};
   SX_TRY(ensure_max_lds(reinterpret_cast<const void*>(wgrad_x3_multi_kernel), done, "hipFuncSetAttribute(wgrad_x3_multi)"));
-  for (int i0 = 0; i0 < n; i0 += WG_X3_MULTI_MAX) {
+  static const int per_launch = std::max(1, std::min(WG_X3_MULTI_MAX, env_int("SX_X3_WG_PER_LAUNCH", WG_X3_MULTI_MAX)));   // diagnostic: 1 = a launch per problem
+  for (int i0 = 0; i0 < n; i0 += per_launch) {
     WgX3MultiArgs A;
     memset(&A, 0, sizeof(A));
-    A.n = std::min(WG_X3_MULTI_MAX, n - i0);
+    A.n = std::min(per_launch, n - i0);
     int blk = 0, smem = 0;
     for (int i = 0; i < A.n; ++i) {
       const WgX3Launch& x = l[i0 + i];
       A.p[i] = x.a; A.variant[i] = x.variant; A.a_tiles[i] = x.a_tiles; A.ab_tiles[i] = x.a_tiles * x.b_tiles;
       A.blk0[i] = blk;
       blk += x.a_tiles * x.b_tiles * x.nsplit;
-      smem = std::max(smem, 2 * x.smem);      // two images per block
+      smem = std::max(smem, x.smem);
     }
     A.blk0[A.n] = blk;
     hipLaunchKernelGGL(wgrad_x3_multi_kernel, dim3(blk), dim3(512), (size_t)smem, st, A);
@@ -693,7 +685,7 @@ int wgrad_launch(int dtype, int mode, int B, int H, int W, int Ca, int Cb, const
     const int PROW = p.MI * 16 * 2 + 16, QROW = 64 * 2 + 16;
     const size_t smem = 2 * ((size_t)a.TP * PROW + (size_t)a.LH * a.LW * QROW);
     const int items8 = cdiv(a.ntaps * p.nbf, 8);
-    const bool fits = 2 * smem <= 160 * 1024 && a.TP * p.MI * 4 <= 4 * 256 && a.LH * a.LW * 16 <= (p.MI == 2 ? 12 : 8) * 256 &&
+    const bool fits = smem <= 160 * 1024 && a.TP * p.MI * 4 <= 4 * 256 && a.LH * a.LW * 16 <= (p.MI == 2 ? 12 : 8) * 256 &&
                       a.TP % 32 == 0 && items8 >= 1 && items8 <= 5;
     if (fits) {
       defer_x3->a = a; defer_x3->variant = p.MI * 16 + items8;
