@@ -127,6 +127,9 @@ __device__ __forceinline__ void gn_stats_flush(const float* sm_stat, int tid, in
 // channels [K, 2K) only feed the centre tap with w2 (data gradient of conv1 + shortcut in one pass)
 enum { WS_PLAIN = 0, WS_DUAL = 1, WS_CENTER = 2, WS_BS = 3, WS_GATHER = 4 };
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var = WS_PLAIN);
+int channel_sum_slots(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, int slots, void* stream);
+int conv3_shortcut_dgrad_slots(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld, const void* packed3_t,
+                               const void* packed1_t, void* dx, int dx_ld, float* ch_sum, int ch_sum_n, int ch_slots, void* stream);
 // sx_conv_forward_gn_bwd_sums with the option to leave the sums to the one-launch GroupNorm backward of small levels
 // (conv_igemm.hip; `deferred` null = always form them)
 int conv_forward_gn_bwd_sums(int dtype, int mode, int B, int H, int W, int Cin, int Cout, const void* x, int x_ld,

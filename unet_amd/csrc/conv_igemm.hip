@@ -760,6 +760,14 @@ extern "C" int sx_conv3_shortcut_forward(int dtype, int B, int H, int W, int Cin
 extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
                                        const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, float* ch_sum,
                                        int ch_sum_n, void* stream) {
+  return sx::conv3_shortcut_dgrad_slots(dtype, B, H, W, C, Cin, dyr, dyr_ld, packed3_t, packed1_t, dx, dx_ld, ch_sum, ch_sum_n, 1, stream);
+}
+
+// ch_slots: ch_sum is [ch_slots][ch_sum_n]; the fused epilogue adds into row 0, a separate channel-sum launch spreads its
+// blocks over all rows (channel_sum_slots)
+int sx::conv3_shortcut_dgrad_slots(int dtype, int B, int H, int W, int C, int Cin, const void* dyr, int dyr_ld,
+                                   const void* packed3_t, const void* packed1_t, void* dx, int dx_ld, float* ch_sum,
+                                   int ch_sum_n, int ch_slots, void* stream) {
   SX_REQUIRE(dyr && packed3_t && packed1_t && dx, "sx_conv3_shortcut_dgrad: null pointer");
   SX_REQUIRE(dyr_ld >= 2 * C, "sx_conv3_shortcut_dgrad: dyr must hold 2*C channels per pixel");
   if (dtype == SX_BF16 && C % 32 == 0 && dyr_ld % 8 == 0 && Cin % 4 == 0 && dx_ld % 4 == 0 && B > 0 && H > 0 && W > 0 &&
@@ -794,7 +802,7 @@ extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, in
     if (rc == 0) {
       if (ch_sum) {
         SX_REQUIRE(ch_sum_n > 0 && ch_sum_n <= Cin && ch_sum_n % 8 == 0 && dx_ld % 8 == 0, "sx_conv3_shortcut_dgrad: bad channel-sum request");
-        SX_TRY(sx_channel_sum(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, stream));
+        SX_TRY(channel_sum_slots(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, ch_slots, stream));
       }
       return SX_OK;
     }
@@ -805,7 +813,7 @@ extern "C" int sx_conv3_shortcut_dgrad(int dtype, int B, int H, int W, int C, in
                          H, W, 1, nullptr, 0, stream));
   if (ch_sum) {
     SX_REQUIRE(ch_sum_n > 0 && ch_sum_n <= Cin && ch_sum_n % 8 == 0 && dx_ld % 8 == 0, "sx_conv3_shortcut_dgrad: bad channel-sum request");
-    SX_TRY(sx_channel_sum(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, stream));
+    SX_TRY(channel_sum_slots(dtype, B, H, W, H, W, ch_sum_n, ch_sum_n, dx, dx_ld, ch_sum, ch_slots, stream));
   }
   return SX_OK;
 }

@@ -159,7 +159,7 @@ __global__ void maxpool_bwd_add_idx_kernel(const unsigned char* __restrict__ idx
 // each thread owns an 8-channel slot and walks pixels (16-byte loads), lanes combine through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ t, int ld, int B, int H, int W, int Hs, int Ws,
-                                                          int C, int C_out, float* __restrict__ out, int pix_per_block) {
+                                                          int C, int C_out, float* __restrict__ out, int pix_per_block, int nslots) {
   __shared__ float red[256 * 8];
   const int64_t npix = (int64_t)B * Hs * Ws;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
   for (int c = threadIdx.x; c < C_out; c += blockDim.x) {
     float s = 0.f;
     for (int l = 0; l < lanes; ++l) s += red[(l * slots + (c >> 3)) * 8 + (c & 7)];
-    atomicAdd(out + c, s);
+    atomicAdd(out + (blockIdx.x % nslots) * C_out + c, s);      // out: [nslots][C_out], block b adds into row b % nslots
   }
 }
 
@@ -278,21 +278,32 @@ extern "C" int sx_maxpool2_backward_add_idx(int dtype, int B, int H, int W, int 
   return SX_OK;
 }
 
+namespace sx {
+int channel_sum_slots(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, int slots, void* stream);
+}
 // out must be zeroed by the caller unless accumulating on purpose.
 extern "C" int sx_channel_sum(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, void* stream) {
-  SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0 && C_out > 0 && C_out <= C, "sx_channel_sum: bad arguments");
+  return channel_sum_slots(dtype, B, H, W, Hs, Ws, C, C_out, t, ld, out, 1, stream);
+}
+
+namespace sx {
+// out: [slots][C_out] partial sums (the caller adds the rows).  Every block ends in C_out same-address atomics, ~13 ns each in
+// the L2's atomic unit; with one row that caps the grid at a block per CU (4 waves per CU: the level-0 fp32 sums ran at
+// 2.3 TB/s), with `slots` rows the grid can be slots times larger for the same queue per address.
+int channel_sum_slots(int dtype, int B, int H, int W, int Hs, int Ws, int C, int C_out, const void* t, int ld, float* out, int slots, void* stream) {
+  SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0 && C_out > 0 && C_out <= C && slots >= 1, "sx_channel_sum: bad arguments");
   if (C % 8 || ld % 8 || C > 2048) { set_error("sx_channel_sum: need C %% 8 == 0 and C <= 2048 (C=%d ld=%d)", C, ld); return SX_ERR_UNSUPPORTED; }
   const int64_t npix = (int64_t)B * Hs * Ws;
-  // every block ends in C_out same-address atomics (~13 ns each in the L2's atomic unit): one block per CU at most
-  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, 512), 256));
+  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, 512), 256 * std::min(slots, 8)));
   const int ppb = (int)cdiv64(npix, blocks);
   blocks = (int)cdiv64(npix, ppb);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SX_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb);
-  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb);
+  if (dtype == SX_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb, slots);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)t, ld, B, H, W, Hs, Ws, C, C_out, out, ppb, slots);
   SX_LAUNCH_CHECK("channel_sum");
   return SX_OK;
 }
+}  // namespace sx
 
 extern "C" int sx_global_avg_pool(int dtype, int B, int HW, int C, const void* x, int ld, float* z, void* stream) {
   SX_REQUIRE(x && z, "sx_global_avg_pool: null pointer");

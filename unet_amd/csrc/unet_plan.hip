@@ -19,6 +19,7 @@
 namespace sx {
 
 static constexpr float GN_EPS = 1e-5f;
+static constexpr int BIAS_SLOTS = 8;      // rows of a transposed convolution's bias-gradient scratch (channel_sum_slots)
 
 struct BlockBuf {   // byte offsets into the workspace
   int64_t Y1, A1, Y2, S, R, O;      // O: block output (skip half of a cat buffer for encoders)
@@ -152,7 +153,7 @@ static int build_plan(const sx_unet_desc* dp, Plan& p) {
   p.sums_begin = off;
   for (auto& b : p.blk) { b.sums1 = take((int64_t)B * b.C * 4 * 4); b.sums2 = take((int64_t)B * b.C * 4 * 4); }
   p.sums_end = off;
-  for (int j = 0; j < D; ++j) p.bias_scr[j] = take((int64_t)p.C[D - 1 - j] * 4);
+  for (int j = 0; j < D; ++j) p.bias_scr[j] = take((int64_t)BIAS_SLOTS * p.C[D - 1 - j] * 4);      // [slot][C]
   p.head_bias_scr = take((int64_t)SX_HEAD_BIAS_SLOTS * p.out_pad * 4);      // [slot][out_ch]: channel_sum fills slot 0, the loss kernel all
   p.bwd_zero_end = off;
   p.dparams = take((int64_t)B * std::max(1, d.P) * 4);
@@ -453,8 +454,8 @@ static int block_backward(const Plan& p, int k, const float* const* params, floa
   }
   if (need_dx) {
     // dX = W1^T (*) dY1 + Ws^T dR in one pass over the [dY1 | dR] buffer
-    SX_TRY(sx_conv3_shortcut_dgrad(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
-                                   at(ws, b.dX), b.dx_ld, ch_sum, ch_sum_n, st));
+    SX_TRY(conv3_shortcut_dgrad_slots(dt, B, b.H, b.W, b.C, b.Cin, at(ws, b.dY1), 2 * b.C, at(wpack, b.w1d), at(wpack, b.wsd),
+                                      at(ws, b.dX), b.dx_ld, ch_sum, ch_sum_n, BIAS_SLOTS, st));
   }
   return SX_OK;
 }
@@ -691,7 +692,7 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     SX_TRY(wq.add(SX_CONV1, d->H, d->W, p.out_pad, p.C[0], d->out_ch, p.C[0], at(ws, p.dpred), p.out_pad,
                   at(ws, last.O), last.o_ld, d->H, d->W, grads[p.out_pidx]));
     if (!(cleared && (flags & SX_BWD_HEAD_BIAS_READY)))
-      SX_TRY(sx_channel_sum(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), stream));
+      SX_TRY(channel_sum_slots(dt, B, d->H, d->W, d->H, d->W, p.out_pad, d->out_ch, at(ws, p.dpred), p.out_pad, (float*)at(ws, p.head_bias_scr), SX_HEAD_BIAS_SLOTS, stream));
     wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch, SX_HEAD_BIAS_SLOTS);
   }
   SX_TRY(sx_conv_forward(dt, SX_CONV1, B, d->H, d->W, p.out_pad, p.C[0], at(ws, p.dpred), p.out_pad, d->H, d->W, at(wpack, p.headd),
@@ -707,8 +708,8 @@ extern "C" int sx_unet_decode_backward(const sx_unet_desc* d, const float* const
     const BlockBuf& prev = p.blk[k - 1];
     if (wg) {
       if (!ride)
-        SX_TRY(sx_channel_sum(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), stream));
-      wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[l]);
+        SX_TRY(channel_sum_slots(dt, B, p.H[l], p.W[l], Hs, Ws, p.C[l], p.C[l], at(ws, p.dcat[l]), 2 * p.C[l], (float*)at(ws, p.bias_scr[j]), BIAS_SLOTS, stream));
+      wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[l], BIAS_SLOTS);
         SX_TRY(wq.add(SX_CONVT_FWD, p.H[l + 1], p.W[l + 1], p.C[l + 1], p.C[l], p.C[l + 1], p.C[l], at(ws, prev.O), prev.o_ld,
                     at(ws, p.dcat[l]), 2 * p.C[l], p.H[l], p.W[l], grads[p.up_pidx[j]]));
     }
@@ -782,7 +783,7 @@ extern "C" int sx_unet_encode_backward(const sx_unet_desc* d, const float* const
     }
   if (wg && (flags & SX_BWD_DEFER_FILM)) {       // ... and so are the head / transposed-conv bias sums
     wq.add_bias((const float*)at(ws, p.head_bias_scr), grads[p.out_pidx + 1], d->out_ch, SX_HEAD_BIAS_SLOTS);
-    for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j]);
+    for (int j = 0; j < D; ++j) wq.add_bias((const float*)at(ws, p.bias_scr[j]), grads[p.up_pidx[j] + 1], p.C[D - 1 - j], BIAS_SLOTS);
   }
   const int ngen = (flags & SX_BWD_DEFER_FILM) ? 2 * D + 1 : D + 1;
   SX_TRY(wq.flush(!film));      // with FiLM: the slab reductions try to ride on the training tail's launch
