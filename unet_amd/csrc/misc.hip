@@ -294,7 +294,8 @@ int channel_sum_slots(int dtype, int B, int H, int W, int Hs, int Ws, int C, int
   SX_REQUIRE(t && out && Hs <= H && Ws <= W && C > 0 && C_out > 0 && C_out <= C && slots >= 1, "sx_channel_sum: bad arguments");
   if (C % 8 || ld % 8 || C > 2048) { set_error("sx_channel_sum: need C %% 8 == 0 and C <= 2048 (C=%d ld=%d)", C, ld); return SX_ERR_UNSUPPORTED; }
   const int64_t npix = (int64_t)B * Hs * Ws;
-  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, 512), 256 * std::min(slots, 8)));
+  // (>= 128 pixels per block with slot rows: the 32x16 level's 64 blocks of 512 pixels took 19.5 us for 16 MB)
+  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(npix, slots > 1 ? 128 : 512), 256 * std::min(slots, 4)));      // (2048 blocks: 18 us at level 0 against 15 with 1024)
   const int ppb = (int)cdiv64(npix, blocks);
   blocks = (int)cdiv64(npix, ppb);
   hipStream_t st = (hipStream_t)stream;
