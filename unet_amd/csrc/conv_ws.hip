@@ -682,6 +682,8 @@ static int ws_pick_k(const ConvArgs& a, hipStream_t st) {
 int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
   if (mode == SX_CONVT_FWD) {
     // four 1x1 GEMMs with a pixel-shuffle store (+ bias); bias needs 16-byte loads of 4 channels
+    // (512 input channels as two K halves, the second accumulating through the pixel-shuffle store: 32 + 51 us against 58 us
+    // on the generic kernel for cfg 5's first transposed convolution -- not kept)
     if (var != WS_PLAIN || a.W < 8 || a.R % 4 || a.accumulate || a.gn_stats || a.KPad % 32 || a.KPad > 256) return 1;
     if (a.bias && ((uintptr_t)a.bias % 16)) return 1;
     return ws_pick_k<1, WS_PLAIN>(a, st);
@@ -695,6 +697,18 @@ int conv_ws_try(const ConvArgs& a, int mode, hipStream_t st, int var) {
       case 1: return ws_pick_tile<4, 1, WS_GATHER>(h, st);
       case 2: return ws_pick_tile<8, 1, WS_GATHER>(h, st);
       case 4: return ws_pick_tile<16, 1, WS_GATHER>(h, st);
+      case 8: {
+        // 256 channels = 32 stationary units: two K halves of 16 (units are [chunk][tap], so the second half starts at unit 16
+        // and 128 channels into every input pixel), the second accumulating (cfg 5: 21.7 + 36.3 us against 85 on the generic kernel)
+        static const int gather_halves = env_int("SX_WS_GATHER_HALVES", 1);
+        if (!gather_halves) return 1;
+        h.K = h.KPad = 128;
+        const int rc = ws_pick_tile<16, 1, WS_GATHER>(h, st);
+        if (rc != 0) return rc;
+        h.x = reinterpret_cast<const bf16*>(a.x) + 128;
+        h.kc0 = 16; h.accumulate = 1;
+        return ws_pick_tile<16, 1, WS_GATHER>(h, st);
+      }
     }
     return 1;
   }
